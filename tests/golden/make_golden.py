@@ -1,0 +1,41 @@
+"""Regenerates the committed golden fixtures.  Needs /root/reference (build container only).
+
+* ref_header_vectors.json  -- printed by oracle/_ref/ref_harness, a program that compiles the
+  reference's own header arithmetic (BoxDim.h, Index1D.h, EvaluatorPairLJ.h,
+  EvaluatorPairExample.h) where it lies under /root/reference.  Doubles are C99 hex floats.
+* lj_forces_and_energies.json -- the "LJ" rows of the reference's data file
+  hoomd/md/pytest/forces_and_energies.json (Mathematica values at r = 0.75 and 1.5).
+* true_pair_list.json -- the reference's data file hoomd/md/pytest/true_pair_list.json
+  (1029 tag pairs of the 7x7x7 simple-cubic lattice at r_cut = 1.1).
+
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_harness")])
+    data = json.loads(out)  # validates
+    with open(os.path.join(HERE, "ref_header_vectors.json"), "w") as f:
+        json.dump(data, f, separators=(",", ":"))
+
+    with open(os.path.join(REF, "hoomd/md/pytest/forces_and_energies.json")) as f:
+        fe = json.load(f)
+    with open(os.path.join(HERE, "lj_forces_and_energies.json"), "w") as f:
+        json.dump({"LJ": fe["LJ"], "distances": [0.75, 1.5], "r_cut": 2.5}, f, indent=1)
+
+    shutil.copyfile(os.path.join(REF, "hoomd/md/pytest/true_pair_list.json"),
+                    os.path.join(HERE, "true_pair_list.json"))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
