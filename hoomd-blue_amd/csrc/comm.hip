@@ -1,0 +1,67 @@
+// comm.hip -- device side of the halo exchange (the CommunicatorGPU role).
+//
+// Contracts: hoomd/CommunicatorGPU.cu:306-372 (ghost plan), :778-875 (pack / pack with periodic
+// shift).  The exchange itself (RCCL all-to-all over xGMI) is driven from the host layer.
+#include "common.cuh"
+
+namespace
+    {
+__global__ void __launch_bounds__(256) ghost_plan_kernel(hmd_ghost_plan_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N)
+        return;
+    const double4 p = hmd_ld4(a.d_pos + idx);
+    const double rg = a.d_r_ghost[hmd_double_as_uint(p.w)];
+    const double gx = rg / a.box.nearest_plane[0], gy = rg / a.box.nearest_plane[1], gz = rg / a.box.nearest_plane[2];
+    hmd_scalar3 zero;
+    zero.x = zero.y = zero.z = 0.0;
+    const double3 f = hmd_make_fraction(a.box, p.x, p.y, p.z, zero);
+    unsigned int plan = 0;
+    if (f.x >= HMD_SUB(1.0, gx))
+        plan |= 1u;
+    if (f.x < gx)
+        plan |= 2u;
+    if (f.y >= HMD_SUB(1.0, gy))
+        plan |= 4u;
+    if (f.y < gy)
+        plan |= 8u;
+    if (f.z >= HMD_SUB(1.0, gz))
+        plan |= 16u;
+    if (f.z < gz)
+        plan |= 32u;
+    a.d_plan[idx] = plan & a.mask;
+    }
+
+__global__ void __launch_bounds__(256) pack_pos_kernel(hmd_pack_pos_args_t a)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_send)
+        return;
+    const double4 p = hmd_ld4(a.d_pos + a.d_send_idx[k]);
+    const hmd_scalar3 sh = a.d_shift_table[a.d_send_shift_id[k]];
+    hmd_st4(a.d_out + k, HMD_ADD(p.x, sh.x), HMD_ADD(p.y, sh.y), HMD_ADD(p.z, sh.z), p.w);
+    }
+    } // namespace
+
+extern "C" int hmd_make_ghost_exchange_plan(const hmd_ghost_plan_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_make_ghost_exchange_plan: args is NULL");
+    HMD_REQUIRE(args->d_plan && args->d_pos && args->d_r_ghost, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_make_ghost_exchange_plan: plan, pos and r_ghost are required");
+    if (args->N == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(ghost_plan_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_positions: args is NULL");
+    HMD_REQUIRE(args->d_out && args->d_pos && args->d_send_idx && args->d_send_shift_id && args->d_shift_table, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_positions: all array arguments are required");
+    if (args->n_send == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(pack_pos_kernel, dim3(hmd_div_up(args->n_send, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }

@@ -1,0 +1,524 @@
+// neighbor_list.hip -- binned neighbor-list build, rebuild check, head list and exclusion filter
+// for gfx950.
+//
+// Contracts: hoomd/md/NeighborListGPUBinned.cu:52-298,756-823 (build),
+// hoomd/md/NeighborListGPU.cu:42-128 (distance check), :355-456 (head list), :158-267 (filter),
+// :270-340 (exclusion table); comparison arithmetic as hoomd/md/NeighborListBinned.cc:150-157 with
+// every product and sum rounded separately, so the neighbor SET of each particle equals the CPU
+// path's bit for bit.
+//
+// Build kernel design (wave64, cell-centric): one wave owns one cell.  The members of the 27
+// adjacent cells (~580 candidates at liquid density) are loaded ONCE, coalesced, into registers
+// -- candidate k lives in lane k%64, register slot k/64 -- and stay there while the wave walks the
+// home cell's particles one at a time.  The home particle's position is wave-uniform (readlane into
+// scalar registers), every lane tests its own candidates, and each 64-candidate slab is compacted
+// with a ballot + lane-rank prefix so that hits are appended contiguously to the padded row
+// nlist[head_i ...].  Candidate traffic from memory is therefore one read per (cell, candidate)
+// instead of one per (particle, candidate); the row writes are dense 4-byte runs.
+#include "common.cuh"
+
+namespace
+    {
+constexpr int NL_MAXK = 12;        // candidate register slots per lane -> 768 candidates per pass
+constexpr int NL_BLOCK = 256;      // 4 waves per workgroup
+constexpr int NL_WAVES = NL_BLOCK / 64;
+
+__device__ __forceinline__ unsigned int rl_u(unsigned int v, unsigned int lane)
+    {
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, (int)lane);
+    }
+__device__ __forceinline__ double rl_d(double v, unsigned int lane)
+    {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)lane);
+    return __hiloint2double(hi, lo);
+    }
+
+// bijective remap of the workgroup id so that each XCD (workgroups are dealt round-robin over 8)
+// walks one contiguous range of cells and neighbouring cells share an L2
+__device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int nb)
+    {
+    const unsigned int q = nb / 8, r = nb % 8, x = b % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+
+template<bool SINGLE_TYPE, bool FILTER_BODY, bool ORTHO>
+__global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc)
+    {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
+    unsigned int* s_excl_all = reinterpret_cast<unsigned int*>(s_raw);
+    unsigned int* s_cell_all = s_excl_all + 64 * NL_WAVES;
+    double* s_rl2 = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
+
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int* s_excl = s_excl_all + 64 * wave;
+    unsigned int* s_cell = s_cell_all + 64 * wave;
+
+    if (!SINGLE_TYPE)
+        {
+        const unsigned int np = a.ntypes * a.ntypes;
+        for (unsigned int t = threadIdx.x; t < np; t += blockDim.x)
+            {
+            const double rc = a.d_r_cut[t];
+            const double rl = HMD_ADD(rc, a.r_buff);
+            s_rl2[t] = (rc > 0.0) ? HMD_MUL(rl, rl) : -1.0;
+            }
+        __syncthreads();
+        }
+    double rl2_single = -1.0;
+    if (SINGLE_TYPE)
+        {
+        const double rc = a.d_r_cut[0];
+        const double rl = HMD_ADD(rc, a.r_buff);
+        rl2_single = (rc > 0.0) ? HMD_MUL(rl, rl) : -1.0;
+        }
+
+    const unsigned int cells_per_block = NL_WAVES / wpc;
+    const unsigned int nblocks = gridDim.x;
+    const unsigned int vb = xcd_remap(blockIdx.x, nblocks);
+    const unsigned int cell = vb * cells_per_block + wave / wpc;
+    const unsigned int sub = wave % wpc;
+    if (cell >= ncells)
+        return;
+
+    const unsigned int n_home = __builtin_amdgcn_readfirstlane(min(a.d_cell_size[cell], a.cli.w));
+    if (n_home == 0)
+        return;
+
+    // ---- adjacency table of this cell: sizes -> exclusive offsets (wave scan) ----
+    const unsigned int n_adj = a.cadji.w;
+    unsigned int adj_cell = 0, adj_size = 0;
+    if (lane < n_adj)
+        {
+        adj_cell = a.d_cell_adj[hmd_idx2(a.cadji, lane, cell)];
+        adj_size = min(a.d_cell_size[adj_cell], a.cli.w);
+        }
+    unsigned int incl = adj_size;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int v = __shfl_up(incl, off);
+        if ((int)lane >= off)
+            incl += v;
+        }
+    s_excl[lane] = incl - adj_size;
+    s_cell[lane] = adj_cell;
+    const unsigned int T = rl_u(incl, 63);
+    // (single wave reads back its own LDS words: no workgroup barrier needed, only the wait
+    //  for the ds_write the compiler inserts before the first dependent ds_read)
+
+    // ---- walk the home cell in slabs of 64 particles (one slab in practice) ----
+    for (unsigned int hbase = 0; hbase < n_home; hbase += 64)
+        {
+        const unsigned int nh = min(n_home - hbase, 64u);
+        double hx = 0, hy = 0, hz = 0;
+        unsigned int hidx = 0xffffffffu, htype = 0, hbody = HMD_NO_BODY, hnmax = 0, cnt = 0;
+        unsigned long long hhead = 0;
+        if (lane < nh)
+            {
+            const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+            const double4 v = hmd_ld4(a.d_cell_xyzf + w);
+            hx = v.x;
+            hy = v.y;
+            hz = v.z;
+            hidx = hmd_double_as_uint(v.w);
+            if (!SINGLE_TYPE || FILTER_BODY)
+                {
+                const uint2 tb = *reinterpret_cast<const uint2*>(a.d_cell_type_body + w);
+                htype = tb.x;
+                hbody = tb.y;
+                }
+            if (hidx < a.N)
+                {
+                hnmax = a.d_Nmax[SINGLE_TYPE ? 0 : htype];
+                hhead = a.d_head_list[hidx];
+                }
+            }
+
+        // ---- candidate passes of up to NL_MAXK*64 ----
+        for (unsigned int pbase = 0; pbase < T; pbase += NL_MAXK * 64)
+            {
+            const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(NL_MAXK * 64)));
+            double cx[NL_MAXK], cy[NL_MAXK], cz[NL_MAXK];
+            unsigned int cj[NL_MAXK], ct[NL_MAXK], cb[NL_MAXK];
+#pragma unroll
+            for (int c = 0; c < NL_MAXK; c++)
+                {
+                cx[c] = cy[c] = cz[c] = __longlong_as_double(0x7ff8000000000000ll); // NaN: never a hit
+                cj[c] = 0xffffffffu;
+                ct[c] = 0;
+                cb[c] = HMD_NO_BODY;
+                if ((unsigned int)(c * 64) < Tp)
+                    {
+                    const unsigned int k = pbase + c * 64 + lane;
+                    if (k < T)
+                        {
+                        // largest table entry with excl <= k
+                        unsigned int lo = 0;
+#pragma unroll
+                        for (unsigned int step = 32; step > 0; step >>= 1)
+                            {
+                            const unsigned int t = lo + step;
+                            if (t < n_adj && s_excl[t] <= k)
+                                lo = t;
+                            }
+                        const unsigned int w = hmd_idx2(a.cli, k - s_excl[lo], s_cell[lo]);
+                        const double4 v = hmd_ld4(a.d_cell_xyzf + w);
+                        cx[c] = v.x;
+                        cy[c] = v.y;
+                        cz[c] = v.z;
+                        cj[c] = hmd_double_as_uint(v.w);
+                        if (!SINGLE_TYPE || FILTER_BODY)
+                            {
+                            const uint2 tb = *reinterpret_cast<const uint2*>(a.d_cell_type_body + w);
+                            ct[c] = tb.x;
+                            cb[c] = tb.y;
+                            }
+                        }
+                    }
+                }
+
+            for (unsigned int i = sub; i < nh; i += wpc)
+                {
+                const unsigned int iu = __builtin_amdgcn_readfirstlane(i);
+                const unsigned int i_idx = rl_u(hidx, iu);
+                if (i_idx >= a.N)
+                    continue; // ghosts get no row
+                const double pix = rl_d(hx, iu), piy = rl_d(hy, iu), piz = rl_d(hz, iu);
+                const unsigned int nmax_i = rl_u(hnmax, iu);
+                const unsigned long long head_i = ((unsigned long long)rl_u((unsigned int)(hhead >> 32), iu) << 32) | rl_u((unsigned int)hhead, iu);
+                unsigned int cnt_i = rl_u(cnt, iu);
+                unsigned int ti = 0, body_i = HMD_NO_BODY;
+                if (!SINGLE_TYPE)
+                    ti = rl_u(htype, iu);
+                if (FILTER_BODY)
+                    body_i = rl_u(hbody, iu);
+                unsigned int* row = a.d_nlist + head_i;
+
+#pragma unroll
+                for (int c = 0; c < NL_MAXK; c++)
+                    {
+                    if ((unsigned int)(c * 64) < Tp)
+                        {
+                        double dx = HMD_SUB(pix, cx[c]);
+                        double dy = HMD_SUB(piy, cy[c]);
+                        double dz = HMD_SUB(piz, cz[c]);
+                        hmd_min_image<ORTHO>(a.box, dx, dy, dz);
+                        const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz));
+                        const double rl2 = SINGLE_TYPE ? rl2_single : s_rl2[hmd_idx2(hmd_index2d_t {a.ntypes, a.ntypes}, ti, ct[c])];
+                        bool hit = (rsq <= rl2) && (cj[c] != i_idx);
+                        if (FILTER_BODY)
+                            hit = hit && !(body_i != HMD_NO_BODY && body_i == cb[c]);
+                        const unsigned long long mask = __ballot(hit);
+                        if (mask)
+                            {
+                            const unsigned int pos = cnt_i + hmd_rank_in_mask(mask);
+                            if (hit && pos < nmax_i)
+                                row[pos] = cj[c];
+                            cnt_i += (unsigned int)__popcll(mask);
+                            }
+                        }
+                    }
+                if (lane == iu)
+                    cnt = cnt_i;
+                }
+            }
+
+        // ---- per-particle results ----
+        if (lane < nh && hidx < a.N && (lane % wpc) == sub)
+            {
+            a.d_n_neigh[hidx] = cnt;
+            if (a.d_last_updated_pos)
+                {
+                // same bits as pos[hidx]: the cell list holds a copy of x,y,z and of the type id
+                const unsigned int t = (SINGLE_TYPE && !FILTER_BODY) ? hmd_double_as_uint(a.d_pos[hidx].w) : htype;
+                hmd_st4(a.d_last_updated_pos + hidx, hx, hy, hz, hmd_uint_as_double(t));
+                }
+            if (cnt >= hnmax)
+                atomicMax(&a.d_conditions[SINGLE_TYPE ? 0 : htype], cnt);
+            }
+        }
+    }
+
+template<bool ORTHO>
+__global__ void __launch_bounds__(256) nlist_check_kernel(hmd_nlist_check_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (idx < a.N)
+        {
+        const double4 cur = hmd_ld4(a.d_pos + idx);
+        const double4 last = hmd_ld4(a.d_last_pos + idx);
+        double dx = HMD_SUB(cur.x, HMD_MUL(a.lambda.x, last.x));
+        double dy = HMD_SUB(cur.y, HMD_MUL(a.lambda.y, last.y));
+        double dz = HMD_SUB(cur.z, HMD_MUL(a.lambda.z, last.z));
+        hmd_min_image<ORTHO>(a.box, dx, dy, dz);
+        const double rmin = a.d_rcut_max[hmd_double_as_uint(cur.w)];
+        const double rmax = HMD_ADD(rmin, a.r_buff);
+        const double delta_max = HMD_SUB(HMD_MUL(rmax, a.lambda_min), rmin) / 2.0;
+        const double maxsq = (delta_max > 0) ? HMD_MUL(delta_max, delta_max) : 0.0;
+        moved = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz)) >= maxsq;
+        }
+    // one atomic per wave that saw a mover
+    if (__ballot(moved) && (threadIdx.x & 63) == 0)
+        atomicMax(a.d_result, a.checkn);
+    }
+
+// ---- head list: exclusive scan of Nmax[type_i] ----
+constexpr unsigned int HL_ITEMS = 8;
+constexpr unsigned int HL_BLOCK = 256;
+constexpr unsigned int HL_TILE = HL_ITEMS * HL_BLOCK;
+
+__device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long* s_wave, unsigned long long& total)
+    {
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned long long t = __shfl_up(incl, off);
+        if ((int)lane >= off)
+            incl += t;
+        }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0;
+    total = 0;
+    for (unsigned int w = 0; w < HL_BLOCK / 64; w++)
+        {
+        if (w < wave)
+            base += s_wave[w];
+        total += s_wave[w];
+        }
+    __syncthreads();
+    return base + incl - v;
+    }
+
+__global__ void __launch_bounds__(HL_BLOCK) head_uniform_kernel(size_t* d_head, size_t* d_req, const unsigned int* d_Nmax, unsigned int N)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nm = d_Nmax[0];
+    if (idx < N)
+        d_head[idx] = (size_t)idx * nm;
+    if (idx == 0)
+        *d_req = (size_t)N * nm;
+    }
+
+__global__ void __launch_bounds__(HL_BLOCK) head_tile_sums_kernel(unsigned long long* d_tile_sum, const unsigned int* d_Nmax, const hmd_scalar4* d_pos, unsigned int N)
+    {
+    __shared__ unsigned long long s_wave[HL_BLOCK / 64];
+    unsigned long long v = 0;
+    const unsigned int base = blockIdx.x * HL_TILE + threadIdx.x * HL_ITEMS;
+    for (unsigned int k = 0; k < HL_ITEMS; k++)
+        if (base + k < N)
+            v += d_Nmax[hmd_double_as_uint(d_pos[base + k].w)];
+    unsigned long long total;
+    block_exclusive_scan(v, s_wave, total);
+    if (threadIdx.x == 0)
+        d_tile_sum[blockIdx.x] = total;
+    }
+
+__global__ void __launch_bounds__(HL_BLOCK) head_scan_tiles_kernel(unsigned long long* d_tile_sum, unsigned int ntiles, size_t* d_req)
+    {
+    __shared__ unsigned long long s_wave[HL_BLOCK / 64];
+    unsigned long long carry = 0;
+    for (unsigned int start = 0; start < ntiles; start += HL_BLOCK)
+        {
+        const unsigned int t = start + threadIdx.x;
+        const unsigned long long v = (t < ntiles) ? d_tile_sum[t] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_exclusive_scan(v, s_wave, total);
+        if (t < ntiles)
+            d_tile_sum[t] = carry + ex;
+        carry += total;
+        }
+    if (threadIdx.x == 0)
+        *d_req = (size_t)carry;
+    }
+
+__global__ void __launch_bounds__(HL_BLOCK) head_write_kernel(size_t* d_head, const unsigned long long* d_tile_sum, const unsigned int* d_Nmax, const hmd_scalar4* d_pos, unsigned int N)
+    {
+    __shared__ unsigned long long s_wave[HL_BLOCK / 64];
+    unsigned int nm[HL_ITEMS];
+    unsigned long long v = 0;
+    const unsigned int base = blockIdx.x * HL_TILE + threadIdx.x * HL_ITEMS;
+#pragma unroll
+    for (unsigned int k = 0; k < HL_ITEMS; k++)
+        {
+        nm[k] = (base + k < N) ? d_Nmax[hmd_double_as_uint(d_pos[base + k].w)] : 0u;
+        v += nm[k];
+        }
+    unsigned long long total;
+    unsigned long long run = d_tile_sum[blockIdx.x] + block_exclusive_scan(v, s_wave, total);
+#pragma unroll
+    for (unsigned int k = 0; k < HL_ITEMS; k++)
+        {
+        if (base + k < N)
+            d_head[base + k] = (size_t)run;
+        run += nm[k];
+        }
+    }
+
+__global__ void __launch_bounds__(256) nlist_filter_kernel(hmd_nlist_filter_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N)
+        return;
+    const unsigned int n_ex = a.d_n_ex[idx];
+    if (n_ex == 0)
+        return;
+    const unsigned int nn = a.d_n_neigh[idx];
+    unsigned int* row = a.d_nlist + a.d_head_list[idx];
+    unsigned int kept = 0;
+    for (unsigned int k = 0; k < nn; k++)
+        {
+        const unsigned int j = row[k];
+        bool excluded = false;
+        for (unsigned int e = 0; e < n_ex; e++)
+            excluded = excluded || (a.d_ex_list[hmd_idx2(a.exli, idx, e)] == j);
+        if (!excluded)
+            {
+            if (kept != k)
+                row[kept] = j;
+            kept++;
+            }
+        }
+    a.d_n_neigh[idx] = kept;
+    }
+
+__global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclusion_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N)
+        return;
+    const unsigned int tag = a.d_tag[idx];
+    const unsigned int n = a.d_n_ex_tag[tag];
+    a.d_n_ex_idx[idx] = n;
+    for (unsigned int o = 0; o < n; o++)
+        a.d_ex_list_idx[hmd_idx2(a.ex_list_indexer, idx, o)] = a.d_rtag[a.d_ex_list_tag[hmd_idx2(a.ex_list_tag_indexer, tag, o)]];
+    }
+
+template<bool ST, bool FB>
+int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s)
+    {
+    const unsigned int cells_per_block = NL_WAVES / wpc;
+    const dim3 grid(hmd_div_up(ncells, cells_per_block));
+    if (hmd_box_is_ortho(a.box))
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc);
+    else
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc);
+    return hmd_launch_status();
+    }
+    } // namespace
+
+extern "C" int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_binned: args is NULL");
+    const hmd_nlist_binned_args_t& a = *args;
+    HMD_REQUIRE(a.d_nlist && a.d_n_neigh && a.d_conditions && a.d_Nmax && a.d_head_list && a.d_pos, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_binned: nlist, n_neigh, conditions, Nmax, head_list and pos are required");
+    HMD_REQUIRE(a.d_cell_size && a.d_cell_xyzf && a.d_cell_adj && a.d_r_cut, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_binned: cell_size, cell_xyzf (w = particle index), cell_adj and r_cut are required");
+    HMD_REQUIRE(a.ntypes >= 1, HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_binned: ntypes must be >= 1");
+    const bool single = (a.ntypes == 1);
+    const bool fb = a.filter_body != 0;
+    HMD_REQUIRE((single && !fb) || a.d_cell_type_body, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_binned: d_cell_type_body is required with more than one type or a body filter");
+    const unsigned int ncells = a.ci.w * a.ci.h * a.ci.d;
+    HMD_REQUIRE(ncells > 0 && a.cli.h == ncells && a.cadji.h == ncells, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_binned: indexers disagree on the number of cells");
+    HMD_REQUIRE(a.cadji.w >= 1 && a.cadji.w <= 64, HMD_ERR_UNSUPPORTED,
+                "hmd_compute_nlist_binned: at most 64 adjacent cells per cell (radius-1 stencils have 27)");
+    HMD_REQUIRE((size_t)a.ntypes * a.ntypes * 8 <= 48 * 1024, HMD_ERR_TOO_LARGE,
+                "hmd_compute_nlist_binned: r_list table exceeds 48 KiB of LDS (ntypes > 78)");
+    if (a.N == 0)
+        return HMD_OK;
+
+    // waves per cell: one fills the chip once there are several cells per SIMD slot
+    unsigned int wpc = 1;
+    if (ncells < 8192)
+        wpc = 2;
+    if (ncells < 2048)
+        wpc = 4;
+    const size_t lds = sizeof(unsigned int) * 128 * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
+    hipStream_t s = (hipStream_t)stream;
+    if (single && !fb)
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s);
+    if (single && fb)
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s);
+    if (!single && !fb)
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s);
+    }
+
+extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_needs_update_check: args is NULL");
+    HMD_REQUIRE(args->d_result && args->d_last_pos && args->d_pos && args->d_rcut_max, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_needs_update_check: result, last_pos, pos and rcut_max are required");
+    if (args->N == 0)
+        return HMD_OK;
+    const dim3 grid(hmd_div_up(args->N, 256));
+    if (hmd_box_is_ortho(args->box))
+        hipLaunchKernelGGL((nlist_check_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *args);
+    else
+        hipLaunchKernelGGL((nlist_check_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" size_t hmd_nlist_head_list_workspace_bytes(unsigned int N)
+    {
+    return sizeof(unsigned long long) * (size_t)(hmd_div_up(N, HL_TILE) + 1);
+    }
+
+extern "C" int hmd_nlist_build_head_list(const hmd_head_list_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_build_head_list: args is NULL");
+    HMD_REQUIRE(args->d_head_list && args->d_req_size_nlist && args->d_Nmax && args->d_pos, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_build_head_list: head_list, req_size_nlist, Nmax and pos are required");
+    hipStream_t s = (hipStream_t)stream;
+    if (args->N == 0)
+        {
+        hipError_t e = hipMemsetAsync(args->d_req_size_nlist, 0, sizeof(size_t), s);
+        return (int)e;
+        }
+    if (args->ntypes == 1)
+        {
+        hipLaunchKernelGGL(head_uniform_kernel, dim3(hmd_div_up(args->N, HL_BLOCK)), dim3(HL_BLOCK), 0, s, args->d_head_list,
+                           args->d_req_size_nlist, args->d_Nmax, args->N);
+        return hmd_launch_status();
+        }
+    const unsigned int ntiles = hmd_div_up(args->N, HL_TILE);
+    HMD_REQUIRE(args->d_workspace && args->workspace_bytes >= hmd_nlist_head_list_workspace_bytes(args->N), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_build_head_list: workspace smaller than hmd_nlist_head_list_workspace_bytes(N)");
+    unsigned long long* tiles = reinterpret_cast<unsigned long long*>(args->d_workspace);
+    hipLaunchKernelGGL(head_tile_sums_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, tiles, args->d_Nmax, args->d_pos, args->N);
+    hipLaunchKernelGGL(head_scan_tiles_kernel, dim3(1), dim3(HL_BLOCK), 0, s, tiles, ntiles, args->d_req_size_nlist);
+    hipLaunchKernelGGL(head_write_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, args->d_head_list, tiles, args->d_Nmax, args->d_pos, args->N);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_nlist_filter(const hmd_nlist_filter_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_filter: args is NULL");
+    HMD_REQUIRE(args->d_n_neigh && args->d_nlist && args->d_head_list && args->d_n_ex && args->d_ex_list, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_filter: all array arguments are required");
+    if (args->N == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(nlist_filter_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_update_exclusion_list(const hmd_update_exclusion_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_update_exclusion_list: args is NULL");
+    HMD_REQUIRE(args->d_tag && args->d_rtag && args->d_n_ex_tag && args->d_ex_list_tag && args->d_n_ex_idx && args->d_ex_list_idx,
+                HMD_ERR_INVALID_ARGUMENT, "hmd_update_exclusion_list: all array arguments are required");
+    if (args->N == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(update_exclusion_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }

@@ -1,0 +1,287 @@
+// pair_force.cuh -- pair-force kernel template for gfx950.
+//
+// Contract: hoomd/md/PotentialPairGPU.cuh:140-404 (kernel semantics) and :579-656 (driver);
+// per-pair arithmetic order as hoomd/md/PotentialPair.h:660-752.  Results agree with the CPU path
+// to rounding (different summation order, fused multiply-adds allowed), well inside 1e-6 relative.
+//
+// Design: TPP lanes share one particle.  Each lane walks the particle's padded neighbor row with
+// stride TPP, so a wave reads 64/TPP rows in TPP*4-byte contiguous pieces, gathers pos[j] with two
+// 16-byte loads, and the partial sums are folded with TPP-wide butterfly shuffles.  Type-pair
+// tables (params, r_cut^2, r_on^2) sit in LDS; with a single particle type they are wave-uniform
+// scalars and the type lookup disappears.  Workgroup ids are remapped so that each XCD walks a
+// contiguous range of particles: with the arrays in cell order its gathers stay inside one L2.
+#ifndef HMD_PAIR_FORCE_CUH
+#define HMD_PAIR_FORCE_CUH
+
+#include "common.cuh"
+
+namespace hmd
+    {
+constexpr int PF_BLOCK = 256;
+
+__device__ __forceinline__ unsigned int pf_xcd_remap(unsigned int b, unsigned int nb)
+    {
+    const unsigned int q = nb / 8, r = nb % 8, x = b % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+    }
+
+template<int TPP> __device__ __forceinline__ double pf_reduce(double v)
+    {
+#pragma unroll
+    for (int m = TPP / 2; m > 0; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+    }
+
+// minimum image for the force loop: fused multiply-adds allowed (hoomd/BoxDim.h:306-325)
+template<bool ORTHO> __device__ __forceinline__ void pf_min_image(const hmd_box_t& b, double& x, double& y, double& z)
+    {
+    if (b.periodic[2])
+        {
+        const double img = rint(z * b.Linv[2]);
+        z -= b.L[2] * img;
+        if (!ORTHO)
+            {
+            y -= b.L[2] * b.yz * img;
+            x -= b.L[2] * b.xz * img;
+            }
+        }
+    if (b.periodic[1])
+        {
+        const double img = rint(y * b.Linv[1]);
+        y -= b.L[1] * img;
+        if (!ORTHO)
+            x -= b.L[1] * b.xy * img;
+        }
+    if (b.periodic[0])
+        x -= b.L[0] * rint(x * b.Linv[0]);
+    }
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE, bool ORTHO>
+__global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a, const typename Ev::param_type* d_params)
+    {
+    typedef typename Ev::param_type param_t;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    const unsigned int np = a.ntypes * a.ntypes;
+    param_t* s_params = reinterpret_cast<param_t*>(s_raw);
+    double* s_rcutsq = reinterpret_cast<double*>(s_raw + (sizeof(param_t) * np + 15) / 16 * 16);
+    double* s_ronsq = s_rcutsq + np;
+
+    param_t p0;
+    double rcutsq0 = 0.0, ronsq0 = 0.0;
+    if (SINGLE_TYPE)
+        {
+        p0 = d_params[0];
+        rcutsq0 = a.d_rcutsq[0];
+        if (SHIFT == 2)
+            ronsq0 = a.d_ronsq[0];
+        }
+    else
+        {
+        for (unsigned int t = threadIdx.x; t < np; t += PF_BLOCK)
+            {
+            s_params[t] = d_params[t];
+            s_rcutsq[t] = a.d_rcutsq[t];
+            s_ronsq[t] = (SHIFT == 2) ? a.d_ronsq[t] : 0.0;
+            }
+        __syncthreads();
+        }
+
+    constexpr unsigned int PPB = PF_BLOCK / TPP; // particles per workgroup
+    const unsigned int vb = pf_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned int idx = vb * PPB + threadIdx.x / TPP;
+    const unsigned int sub = threadIdx.x % TPP;
+    const bool active = idx < a.N;
+
+    double fx = 0, fy = 0, fz = 0, pe = 0;
+    double vxx = 0, vxy = 0, vxz = 0, vyy = 0, vyz = 0, vzz = 0;
+
+    if (active)
+        {
+        const unsigned int nn = a.d_n_neigh[idx];
+        const double4 pi = hmd_ld4(a.d_pos + idx);
+        const unsigned int ti = SINGLE_TYPE ? 0u : hmd_double_as_uint(pi.w);
+        double qi = 0.0;
+        if (Ev::needsCharge())
+            qi = a.d_charge[idx];
+        const unsigned int* row = a.d_nlist + a.d_head_list[idx];
+
+#pragma unroll 4
+        for (unsigned int k = sub; k < nn; k += TPP)
+            {
+            const unsigned int j = row[k];
+            const double4 pj = hmd_ld4(a.d_pos + j);
+            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            pf_min_image<ORTHO>(a.box, dx, dy, dz);
+            const double rsq = dx * dx + dy * dy + dz * dz;
+
+            double rcutsq, ronsq = 0.0;
+            const param_t* prm;
+            if (SINGLE_TYPE)
+                {
+                rcutsq = rcutsq0;
+                ronsq = ronsq0;
+                prm = &p0;
+                }
+            else
+                {
+                const unsigned int tp = hmd_double_as_uint(pj.w) * a.ntypes + ti;
+                rcutsq = s_rcutsq[tp];
+                if (SHIFT == 2)
+                    ronsq = s_ronsq[tp];
+                prm = s_params + tp;
+                }
+
+            bool energy_shift = false;
+            if (SHIFT == 1)
+                energy_shift = true;
+            else if (SHIFT == 2)
+                energy_shift = ronsq > rcutsq;
+
+            double fdr = 0.0, eng = 0.0;
+            Ev ev(rsq, rcutsq, *prm);
+            if (Ev::needsCharge())
+                ev.setCharge(qi, a.d_charge[j]);
+            const bool evaluated = ev.evalForceAndEnergy(fdr, eng, energy_shift);
+            if (!evaluated)
+                {
+                fdr = 0.0;
+                eng = 0.0;
+                }
+
+            if (SHIFT == 2)
+                {
+                if (evaluated && rsq >= ronsq && rsq < rcutsq)
+                    {
+                    // XPLOR switching, hoomd/md/PotentialPair.h:711-737
+                    const double d3 = (rcutsq - ronsq) * (rcutsq - ronsq) * (rcutsq - ronsq);
+                    const double denom_inv = 1.0 / d3;
+                    const double d = rsq - rcutsq;
+                    const double sw = d * d * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * denom_inv;
+                    const double dsw = 12.0 * (rsq - ronsq) * d * denom_inv;
+                    fdr = sw * fdr - dsw * eng;
+                    eng = eng * sw;
+                    }
+                }
+
+            fx += dx * fdr;
+            fy += dy * fdr;
+            fz += dz * fdr;
+            pe += eng;
+            if (VIRIAL)
+                {
+                const double f2 = 0.5 * fdr;
+                vxx += dx * dx * f2;
+                vxy += dx * dy * f2;
+                vxz += dx * dz * f2;
+                vyy += dy * dy * f2;
+                vyz += dy * dz * f2;
+                vzz += dz * dz * f2;
+                }
+            }
+        pe *= 0.5;
+        }
+
+    fx = pf_reduce<TPP>(fx);
+    fy = pf_reduce<TPP>(fy);
+    fz = pf_reduce<TPP>(fz);
+    pe = pf_reduce<TPP>(pe);
+    if (active && sub == 0)
+        hmd_st4(a.d_force + idx, fx, fy, fz, pe);
+
+    if (VIRIAL)
+        {
+        vxx = pf_reduce<TPP>(vxx);
+        vxy = pf_reduce<TPP>(vxy);
+        vxz = pf_reduce<TPP>(vxz);
+        vyy = pf_reduce<TPP>(vyy);
+        vyz = pf_reduce<TPP>(vyz);
+        vzz = pf_reduce<TPP>(vzz);
+        if (active && sub == 0)
+            {
+            a.d_virial[0 * a.virial_pitch + idx] = vxx;
+            a.d_virial[1 * a.virial_pitch + idx] = vxy;
+            a.d_virial[2 * a.virial_pitch + idx] = vxz;
+            a.d_virial[3 * a.virial_pitch + idx] = vyy;
+            a.d_virial[4 * a.virial_pitch + idx] = vyz;
+            a.d_virial[5 * a.virial_pitch + idx] = vzz;
+            }
+        }
+    }
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP>
+int pf_launch3(const hmd_pair_args_t& a, const typename Ev::param_type* d_params, hipStream_t s)
+    {
+    const unsigned int np = a.ntypes * a.ntypes;
+    const bool single = a.ntypes == 1;
+    const size_t lds = single ? 0 : (sizeof(typename Ev::param_type) * np + 15) / 16 * 16 + 2 * sizeof(double) * np;
+    const dim3 grid(hmd_div_up(a.N, PF_BLOCK / TPP));
+    const bool ortho = hmd_box_is_ortho(a.box);
+    if (single && ortho)
+        hipLaunchKernelGGL((pair_force_kernel<Ev, SHIFT, VIRIAL, TPP, true, true>), grid, dim3(PF_BLOCK), lds, s, a, d_params);
+    else if (single)
+        hipLaunchKernelGGL((pair_force_kernel<Ev, SHIFT, VIRIAL, TPP, true, false>), grid, dim3(PF_BLOCK), lds, s, a, d_params);
+    else if (ortho)
+        hipLaunchKernelGGL((pair_force_kernel<Ev, SHIFT, VIRIAL, TPP, false, true>), grid, dim3(PF_BLOCK), lds, s, a, d_params);
+    else
+        hipLaunchKernelGGL((pair_force_kernel<Ev, SHIFT, VIRIAL, TPP, false, false>), grid, dim3(PF_BLOCK), lds, s, a, d_params);
+    return hmd_launch_status();
+    }
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL>
+int pf_launch2(const hmd_pair_args_t& a, const typename Ev::param_type* d_params, unsigned int tpp, hipStream_t s)
+    {
+    switch (tpp)
+        {
+    case 1:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 1>(a, d_params, s);
+    case 2:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 2>(a, d_params, s);
+    case 4:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 4>(a, d_params, s);
+    case 8:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 8>(a, d_params, s);
+    case 16:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 16>(a, d_params, s);
+    case 32:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 32>(a, d_params, s);
+    default:
+        return pf_launch3<Ev, SHIFT, VIRIAL, 64>(a, d_params, s);
+        }
+    }
+
+// Driver shared by every evaluator's extern "C" entry point.
+template<class Ev> int launch_pair_forces(const hmd_pair_args_t* args, const typename Ev::param_type* d_params, void* stream, const char* who)
+    {
+    HMD_REQUIRE(args && d_params, HMD_ERR_INVALID_ARGUMENT, "pair forces: args and d_params are required");
+    const hmd_pair_args_t& a = *args;
+    HMD_REQUIRE(a.d_force && a.d_pos && a.d_n_neigh && a.d_nlist && a.d_head_list && a.d_rcutsq, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces: force, pos, n_neigh, nlist, head_list and rcutsq are required");
+    HMD_REQUIRE(a.shift_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces: shift_mode must be 0 (none), 1 (shift) or 2 (xplor)");
+    HMD_REQUIRE(a.shift_mode != 2 || a.d_ronsq, HMD_ERR_INVALID_ARGUMENT, "pair forces: xplor needs d_ronsq");
+    HMD_REQUIRE(!a.compute_virial || a.d_virial, HMD_ERR_INVALID_ARGUMENT, "pair forces: compute_virial needs d_virial");
+    HMD_REQUIRE(!Ev::needsCharge() || a.d_charge, HMD_ERR_INVALID_ARGUMENT, "pair forces: this evaluator needs d_charge");
+    HMD_REQUIRE(a.ntypes >= 1, HMD_ERR_INVALID_ARGUMENT, "pair forces: ntypes must be >= 1");
+    unsigned int tpp = a.threads_per_particle ? a.threads_per_particle : 8;
+    HMD_REQUIRE(tpp <= 64 && (tpp & (tpp - 1)) == 0, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces: threads_per_particle must be a power of two in [1, 64]");
+    const size_t lds = (sizeof(typename Ev::param_type) + 16) * (size_t)a.ntypes * a.ntypes + 16;
+    HMD_REQUIRE(lds <= 64 * 1024, HMD_ERR_TOO_LARGE, "pair forces: type-pair tables exceed 64 KiB of LDS");
+    (void)who;
+    if (a.N == 0)
+        return HMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vir = a.compute_virial != 0;
+    switch (a.shift_mode)
+        {
+    case 0:
+        return vir ? pf_launch2<Ev, 0, true>(a, d_params, tpp, s) : pf_launch2<Ev, 0, false>(a, d_params, tpp, s);
+    case 1:
+        return vir ? pf_launch2<Ev, 1, true>(a, d_params, tpp, s) : pf_launch2<Ev, 1, false>(a, d_params, tpp, s);
+    default:
+        return vir ? pf_launch2<Ev, 2, true>(a, d_params, tpp, s) : pf_launch2<Ev, 2, false>(a, d_params, tpp, s);
+        }
+    }
+    } // namespace hmd
+
+#endif

@@ -1,0 +1,10 @@
+// pair_force_example.hip -- what a pair-potential plugin ships: one translation unit that
+// instantiates the driver for its evaluator, as
+// example_plugins/pair_plugin/PotentialPairExampleGPUKernel.cu:13-15 does in the reference.
+#include "evaluators.cuh"
+#include "pair_force.cuh"
+
+extern "C" int hmd_compute_pair_forces_example(const hmd_pair_args_t* args, const hmd_example_params_t* d_params, void* stream)
+    {
+    return hmd::launch_pair_forces<hmd::EvaluatorPairExample>(args, d_params, stream, "example_pair");
+    }

@@ -1,0 +1,208 @@
+"""ctypes mirror of include/hoomd_amd.h.
+
+Loads ``libhoomd_amd.so`` (the gfx950 kernel-driver library) from the package directory and
+declares every struct and entry point of the C ABI.  There is no fallback: if the library is
+missing the import fails, and nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libhoomd_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP kernel library first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C hoomd-blue_amd/csrc)")
+
+lib = C.CDLL(LIB_PATH)
+
+NO_BODY = 0xFFFFFFFF
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_TOO_LARGE = -1, -2, -3
+
+vp = C.c_void_p
+u32 = C.c_uint
+f64 = C.c_double
+
+
+class Scalar3(C.Structure):
+    _fields_ = [("x", f64), ("y", f64), ("z", f64)]
+
+
+class Box(C.Structure):
+    _fields_ = [("lo", f64 * 3), ("hi", f64 * 3), ("L", f64 * 3), ("Linv", f64 * 3), ("xy", f64), ("xz", f64),
+                ("yz", f64), ("nearest_plane", f64 * 3), ("periodic", C.c_ubyte * 3), ("pad_", C.c_ubyte * 5)]
+
+    @classmethod
+    def from_L(cls, Lx, Ly, Lz, xy=0.0, xz=0.0, yz=0.0, periodic=(1, 1, 1)):
+        b = cls()
+        lib.hmd_box_init(C.byref(b), f64(Lx), f64(Ly), f64(Lz), f64(xy), f64(xz), f64(yz))
+        for d in range(3):
+            b.periodic[d] = int(periodic[d])
+        return b
+
+    @classmethod
+    def from_lo_hi(cls, lo, hi, periodic=(1, 1, 1)):
+        b = cls()
+        lib.hmd_box_init(C.byref(b), f64(1), f64(1), f64(1), f64(0), f64(0), f64(0))
+        lib.hmd_box_set_lo_hi(C.byref(b), (f64 * 3)(*lo), (f64 * 3)(*hi))
+        for d in range(3):
+            b.periodic[d] = int(periodic[d])
+        return b
+
+
+class Index2D(C.Structure):
+    _fields_ = [("w", u32), ("h", u32)]
+
+
+class Index3D(C.Structure):
+    _fields_ = [("w", u32), ("h", u32), ("d", u32)]
+
+
+class CellListArgs(C.Structure):
+    _fields_ = [("d_cell_size", vp), ("d_xyzf", vp), ("d_type_body", vp), ("d_cell_orientation", vp),
+                ("d_cell_idx", vp), ("d_conditions", vp), ("d_pos", vp), ("d_orientation", vp), ("d_charge", vp),
+                ("d_diameter", vp), ("d_body", vp), ("N", u32), ("n_ghost", u32), ("Nmax", u32),
+                ("flag_charge", C.c_int), ("flag_type", C.c_int), ("box", Box), ("ci", Index3D), ("cli", Index2D),
+                ("ghost_width", Scalar3), ("block_size", u32), ("clear_cell_size", C.c_int)]
+
+
+class SortCellListArgs(C.Structure):
+    _fields_ = [("d_cell_size", vp), ("d_xyzf", vp), ("d_type_body", vp), ("d_cell_idx", vp), ("ci", Index3D),
+                ("cli", Index2D), ("flag_is_index", C.c_int)]
+
+
+class NlistCheckArgs(C.Structure):
+    _fields_ = [("d_result", vp), ("d_last_pos", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_rcut_max", vp),
+                ("r_buff", f64), ("ntypes", u32), ("lambda_min", f64), ("lam", Scalar3), ("checkn", u32)]
+
+
+class HeadListArgs(C.Structure):
+    _fields_ = [("d_head_list", vp), ("d_req_size_nlist", vp), ("d_Nmax", vp), ("d_pos", vp), ("N", u32),
+                ("ntypes", u32), ("d_workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
+class NlistBinnedArgs(C.Structure):
+    _fields_ = [("d_nlist", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp), ("d_Nmax", vp),
+                ("d_head_list", vp), ("d_pos", vp), ("d_body", vp), ("N", u32), ("d_cell_size", vp),
+                ("d_cell_xyzf", vp), ("d_cell_idx", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp),
+                ("ci", Index3D), ("cli", Index2D), ("cadji", Index2D), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
+                ("ntypes", u32), ("threads_per_particle", u32), ("block_size", u32), ("filter_body", C.c_int),
+                ("ghost_width", Scalar3)]
+
+
+class NlistFilterArgs(C.Structure):
+    _fields_ = [("d_n_neigh", vp), ("d_nlist", vp), ("d_head_list", vp), ("d_n_ex", vp), ("d_ex_list", vp),
+                ("exli", Index2D), ("N", u32), ("block_size", u32)]
+
+
+class UpdateExclusionArgs(C.Structure):
+    _fields_ = [("d_tag", vp), ("d_rtag", vp), ("d_n_ex_tag", vp), ("d_ex_list_tag", vp),
+                ("ex_list_tag_indexer", Index2D), ("d_n_ex_idx", vp), ("d_ex_list_idx", vp),
+                ("ex_list_indexer", Index2D), ("N", u32)]
+
+
+class PairArgs(C.Structure):
+    _fields_ = [("d_force", vp), ("d_virial", vp), ("virial_pitch", C.c_size_t), ("N", u32), ("n_max", u32),
+                ("d_pos", vp), ("d_charge", vp), ("box", Box), ("d_n_neigh", vp), ("d_nlist", vp), ("d_head_list", vp),
+                ("d_rcutsq", vp), ("d_ronsq", vp), ("size_neigh_list", C.c_size_t), ("ntypes", u32),
+                ("block_size", u32), ("shift_mode", u32), ("compute_virial", u32), ("threads_per_particle", u32)]
+
+
+class ForceList(C.Structure):
+    _fields_ = [("f", vp * 6), ("t", vp * 6), ("v", vp * 6), ("vpitch", C.c_size_t * 6)]
+
+
+class SumNetForceArgs(C.Structure):
+    _fields_ = [("d_net_force", vp), ("d_net_virial", vp), ("net_virial_pitch", C.c_size_t), ("d_net_torque", vp),
+                ("force_list", ForceList), ("nparticles", u32), ("clear", C.c_int), ("compute_virial", C.c_int)]
+
+
+class StepOneArgs(C.Structure):
+    _fields_ = [("d_pos", vp), ("d_vel", vp), ("d_accel", vp), ("d_image", vp), ("d_group_members", vp),
+                ("group_size", u32), ("box", Box), ("block_size", u32), ("rescale_factor", f64), ("deltaT", f64),
+                ("use_limit", C.c_int), ("maximum_displacement", f64)]
+
+
+class StepTwoArgs(C.Structure):
+    _fields_ = [("d_vel", vp), ("d_accel", vp), ("d_group_members", vp), ("group_size", u32), ("d_net_force", vp),
+                ("block_size", u32), ("deltaT", f64), ("rescale_factor", f64)]
+
+
+class ThermoArgs(C.Structure):
+    _fields_ = [("d_out", vp), ("d_scratch", vp), ("d_vel", vp), ("d_net_force", vp), ("d_net_virial", vp),
+                ("net_virial_pitch", C.c_size_t), ("d_group_members", vp), ("group_size", u32)]
+
+
+class CellOrderArgs(C.Structure):
+    _fields_ = [("d_order", vp), ("d_cell_offset", vp), ("d_cell_size", vp), ("d_cell_xyzf", vp), ("ci", Index3D),
+                ("cli", Index2D), ("N", u32), ("d_workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
+class GhostPlanArgs(C.Structure):
+    _fields_ = [("d_plan", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_r_ghost", vp), ("ntypes", u32),
+                ("mask", u32)]
+
+
+class PackPosArgs(C.Structure):
+    _fields_ = [("d_out", vp), ("d_pos", vp), ("d_send_idx", vp), ("d_send_shift_id", vp), ("d_shift_table", vp),
+                ("n_send", u32)]
+
+
+# every symbol the header declares, with its signature
+_SIGNATURES = {
+    "hmd_box_init": (None, [C.POINTER(Box), f64, f64, f64, f64, f64, f64]),
+    "hmd_box_set_lo_hi": (None, [C.POINTER(Box), C.POINTER(f64), C.POINTER(f64)]),
+    "hmd_abi_version": (C.c_int, []),
+    "hmd_last_error": (C.c_char_p, []),
+    "hmd_compute_cell_list": (C.c_int, [C.POINTER(CellListArgs), vp]),
+    "hmd_sort_cell_list": (C.c_int, [C.POINTER(SortCellListArgs), vp]),
+    "hmd_nlist_needs_update_check": (C.c_int, [C.POINTER(NlistCheckArgs), vp]),
+    "hmd_nlist_head_list_workspace_bytes": (C.c_size_t, [u32]),
+    "hmd_nlist_build_head_list": (C.c_int, [C.POINTER(HeadListArgs), vp]),
+    "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
+    "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
+    "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
+    "hmd_compute_pair_forces_lj": (C.c_int, [C.POINTER(PairArgs), vp, vp]),
+    "hmd_compute_pair_forces_example": (C.c_int, [C.POINTER(PairArgs), vp, vp]),
+    "hmd_integrator_sum_net_force": (C.c_int, [C.POINTER(SumNetForceArgs), vp]),
+    "hmd_nvt_rescale_step_one": (C.c_int, [C.POINTER(StepOneArgs), vp]),
+    "hmd_nvt_rescale_step_two": (C.c_int, [C.POINTER(StepTwoArgs), vp]),
+    "hmd_compute_accelerations": (C.c_int, [vp, vp, vp, u32, vp]),
+    "hmd_thermo_scratch_bytes": (C.c_size_t, []),
+    "hmd_compute_thermo": (C.c_int, [C.POINTER(ThermoArgs), vp]),
+    "hmd_cell_order_workspace_bytes": (C.c_size_t, [u32]),
+    "hmd_cell_order": (C.c_int, [C.POINTER(CellOrderArgs), vp]),
+    "hmd_gather_rows": (C.c_int, [vp, vp, vp, u32, u32, vp]),
+    "hmd_build_rtag": (C.c_int, [vp, vp, u32, vp]),
+    "hmd_make_ghost_exchange_plan": (C.c_int, [C.POINTER(GhostPlanArgs), vp]),
+    "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def check(code, what=""):
+    """Raise on a non-zero return of a driver call."""
+    if code == 0:
+        return
+    if code < 0:
+        raise KernelError(f"{what}: {lib.hmd_last_error().decode()} (code {code})")
+    raise KernelError(f"{what}: HIP error {code}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array as c_void_p; None -> NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)

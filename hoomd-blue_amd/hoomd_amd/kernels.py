@@ -1,0 +1,286 @@
+"""Thin torch-tensor front end of the C ABI (include/hoomd_amd.h).
+
+Every function here builds the argument block of one driver and launches it on the current HIP
+stream of the tensors' device.  Device memory is plain ``torch`` tensors; nothing in this module
+computes anything itself.  Used by the Python-level halo exchange and by the GPU parity tests.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import Box, Index2D, Index3D, Scalar3, check, ptr
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _s3(v):
+    return Scalar3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def pack_pos(xyz, typeid=None, device="cuda"):
+    """(N,3) float64 + type ids -> (N,4) tensor with the id bit-stuffed into w."""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((xyz.shape[0], 4), dtype=np.float64)
+    out[:, :3] = xyz
+    if typeid is not None:
+        w = (np.asarray(typeid, dtype=np.int64) & 0xFFFFFFFF)
+        out[:, 3] = w.view(np.float64) if w.ndim else w
+    return torch.from_numpy(out).to(device)
+
+
+def int_w(col):
+    """Low 32 bits of each float64 of a (host) array."""
+    a = np.ascontiguousarray(col, dtype=np.float64)
+    return (a.view(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def compute_cell_list(pos, N, n_ghost, box, dim, Nmax, ghost_width=(0, 0, 0), flag_charge=False, flag_type=False,
+                      charge=None, body=None, want_type_body=True, want_idx=False):
+    dev = pos.device
+    ncells = dim[0] * dim[1] * dim[2]
+    cell_size = torch.zeros(ncells, dtype=torch.int32, device=dev)
+    xyzf = torch.zeros((ncells, Nmax, 4), dtype=torch.float64, device=dev)
+    tb = torch.zeros((ncells, Nmax, 2), dtype=torch.int32, device=dev) if want_type_body else None
+    idx = torch.zeros((ncells, Nmax), dtype=torch.int32, device=dev) if want_idx else None
+    cond = torch.zeros(3, dtype=torch.int32, device=dev)
+    a = _abi.CellListArgs()
+    a.d_cell_size, a.d_xyzf, a.d_type_body, a.d_cell_idx = ptr(cell_size), ptr(xyzf), ptr(tb), ptr(idx)
+    a.d_conditions, a.d_pos, a.d_charge, a.d_body = ptr(cond), ptr(pos), ptr(charge), ptr(body)
+    a.N, a.n_ghost, a.Nmax = N, n_ghost, Nmax
+    a.flag_charge, a.flag_type = int(flag_charge), int(flag_type)
+    a.box = box
+    a.ci = Index3D(*dim)
+    a.cli = Index2D(Nmax, ncells)
+    a.ghost_width = _s3(ghost_width)
+    a.clear_cell_size = 1
+    check(_abi.lib.hmd_compute_cell_list(C.byref(a), _stream(pos)), "hmd_compute_cell_list")
+    return dict(cell_size=cell_size, xyzf=xyzf, type_body=tb, idx=idx, conditions=cond, Nmax=Nmax, dim=tuple(dim))
+
+
+def cell_list_auto(pos, N, n_ghost, box, dim, ghost_width=(0, 0, 0), **kw):
+    """Grow Nmax until nothing overflows (hoomd/CellList.cc:184-199)."""
+    ncells = dim[0] * dim[1] * dim[2]
+    Nmax = max(1, int(np.ceil((N + n_ghost) / ncells)))
+    while True:
+        r = compute_cell_list(pos, N, n_ghost, box, dim, Nmax, ghost_width, **kw)
+        c = r["conditions"].cpu().numpy().astype(np.uint32)
+        if c[0] > Nmax:
+            Nmax = int(c[0])
+            continue
+        return r
+
+
+def sort_cell_list(cl, flag_is_index=True):
+    a = _abi.SortCellListArgs()
+    a.d_cell_size, a.d_xyzf, a.d_type_body, a.d_cell_idx = ptr(cl["cell_size"]), ptr(cl["xyzf"]), ptr(cl["type_body"]), ptr(cl["idx"])
+    a.ci = Index3D(*cl["dim"])
+    a.cli = Index2D(cl["Nmax"], cl["cell_size"].numel())
+    a.flag_is_index = int(flag_is_index)
+    check(_abi.lib.hmd_sort_cell_list(C.byref(a), _stream(cl["xyzf"])), "hmd_sort_cell_list")
+
+
+def build_head_list(pos, N, Nmax_t):
+    dev = pos.device
+    head = torch.zeros(max(N, 1), dtype=torch.int64, device=dev)
+    req = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws_bytes = _abi.lib.hmd_nlist_head_list_workspace_bytes(N)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    a = _abi.HeadListArgs()
+    a.d_head_list, a.d_req_size_nlist, a.d_Nmax, a.d_pos = ptr(head), ptr(req), ptr(Nmax_t), ptr(pos)
+    a.N, a.ntypes = N, Nmax_t.numel()
+    a.d_workspace, a.workspace_bytes = ptr(ws), ws_bytes
+    check(_abi.lib.hmd_nlist_build_head_list(C.byref(a), _stream(pos)), "hmd_nlist_build_head_list")
+    return head, int(req.item())
+
+
+def nlist_binned(pos, N, box, r_cut, r_buff, cl, adj, n_ghost=0, ghost_width=(0, 0, 0), body=None, filter_body=False):
+    """Full protocol: head list -> build -> grow Nmax on overflow -> rebuild
+    (hoomd/md/NeighborList.cc:406-434).  ``cl`` from compute_cell_list, ``adj`` (ncells, n_adj) int32."""
+    dev = pos.device
+    r_cut_t = torch.as_tensor(np.asarray(r_cut, dtype=np.float64), device=dev).contiguous()
+    nt = r_cut_t.shape[0]
+    Nmax_t = torch.full((nt,), 4, dtype=torch.int32, device=dev)
+    ncells = cl["cell_size"].numel()
+    last_pos = torch.zeros((max(N, 1), 4), dtype=torch.float64, device=dev)
+    n_builds = 0
+    while True:
+        head, total = build_head_list(pos, N, Nmax_t)
+        nlist = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+        n_neigh = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+        cond = torch.zeros(nt, dtype=torch.int32, device=dev)
+        a = _abi.NlistBinnedArgs()
+        a.d_nlist, a.d_n_neigh, a.d_last_updated_pos, a.d_conditions = ptr(nlist), ptr(n_neigh), ptr(last_pos), ptr(cond)
+        a.d_Nmax, a.d_head_list, a.d_pos, a.d_body, a.N = ptr(Nmax_t), ptr(head), ptr(pos), ptr(body), N
+        a.d_cell_size, a.d_cell_xyzf, a.d_cell_type_body, a.d_cell_adj = ptr(cl["cell_size"]), ptr(cl["xyzf"]), ptr(cl["type_body"]), ptr(adj)
+        a.ci = Index3D(*cl["dim"])
+        a.cli = Index2D(cl["Nmax"], ncells)
+        a.cadji = Index2D(adj.shape[1], ncells)
+        a.box = box
+        a.d_r_cut, a.r_buff, a.ntypes = ptr(r_cut_t), float(r_buff), nt
+        a.filter_body = int(filter_body)
+        a.ghost_width = _s3(ghost_width)
+        check(_abi.lib.hmd_compute_nlist_binned(C.byref(a), _stream(pos)), "hmd_compute_nlist_binned")
+        n_builds += 1
+        c = cond.cpu().numpy().astype(np.int64)
+        nm = Nmax_t.cpu().numpy().astype(np.int64)
+        over = c > nm
+        if over.any():
+            # hoomd/md/NeighborList.cc:1601-1617
+            nm[over] = np.where(c[over] > 4, (c[over] + 3) & ~3, 4)
+            Nmax_t = torch.as_tensor(nm.astype(np.int32), device=dev)
+            continue
+        break
+    return dict(n_neigh=n_neigh, nlist=nlist, head=head, Nmax=Nmax_t, last_pos=last_pos, n_builds=n_builds)
+
+
+def nlist_check(pos, last_pos, N, box, rcut_max, r_buff, lam=(1.0, 1.0, 1.0), checkn=1):
+    dev = pos.device
+    res = torch.zeros(1, dtype=torch.int32, device=dev)
+    rcm = torch.as_tensor(np.asarray(rcut_max, dtype=np.float64), device=dev)
+    a = _abi.NlistCheckArgs()
+    a.d_result, a.d_last_pos, a.d_pos, a.N, a.box = ptr(res), ptr(last_pos), ptr(pos), N, box
+    a.d_rcut_max, a.r_buff, a.ntypes = ptr(rcm), float(r_buff), rcm.numel()
+    a.lambda_min = float(min(lam))
+    a.lam = _s3(lam)
+    a.checkn = checkn
+    check(_abi.lib.hmd_nlist_needs_update_check(C.byref(a), _stream(pos)), "hmd_nlist_needs_update_check")
+    return int(res.item())
+
+
+def nlist_filter(N, head, n_ex, ex_list, n_neigh, nlist):
+    """ex_list: (n_ex_max, pitch) int32 with pitch >= N (Index2D(pitch, height))."""
+    a = _abi.NlistFilterArgs()
+    a.d_n_neigh, a.d_nlist, a.d_head_list, a.d_n_ex, a.d_ex_list = ptr(n_neigh), ptr(nlist), ptr(head), ptr(n_ex), ptr(ex_list)
+    a.exli = Index2D(ex_list.shape[1], ex_list.shape[0])
+    a.N = N
+    check(_abi.lib.hmd_nlist_filter(C.byref(a), _stream(nlist)), "hmd_nlist_filter")
+
+
+def pair_forces(evaluator, pos, N, box, n_neigh, nlist, head, params, rcutsq, ronsq=None, shift_mode=0,
+                compute_virial=True, tpp=0, n_total=None):
+    dev = pos.device
+    n_total = pos.shape[0] if n_total is None else n_total
+    prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
+    rc = torch.as_tensor(np.asarray(rcutsq, dtype=np.float64), device=dev).contiguous()
+    nt = rc.shape[0]
+    ro = torch.as_tensor(np.asarray(ronsq if ronsq is not None else np.zeros((nt, nt)), dtype=np.float64), device=dev).contiguous()
+    force = torch.full((n_total, 4), float("nan"), dtype=torch.float64, device=dev)
+    virial = torch.full((6, n_total), float("nan"), dtype=torch.float64, device=dev) if compute_virial else None
+    a = _abi.PairArgs()
+    a.d_force, a.d_virial, a.virial_pitch = ptr(force), ptr(virial), n_total
+    a.N, a.n_max, a.d_pos, a.box = N, n_total, ptr(pos), box
+    a.d_n_neigh, a.d_nlist, a.d_head_list = ptr(n_neigh), ptr(nlist), ptr(head)
+    a.d_rcutsq, a.d_ronsq, a.size_neigh_list, a.ntypes = ptr(rc), ptr(ro), nlist.numel(), nt
+    a.shift_mode, a.compute_virial, a.threads_per_particle = shift_mode, int(compute_virial), tpp
+    fn = {"lj": _abi.lib.hmd_compute_pair_forces_lj, "example": _abi.lib.hmd_compute_pair_forces_example}[evaluator]
+    check(fn(C.byref(a), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_" + evaluator)
+    return force, virial
+
+
+def sum_net_force(forces, virials=None, net_force=None, net_virial=None, clear=True):
+    dev = forces[0].device
+    n = forces[0].shape[0]
+    nf = net_force if net_force is not None else torch.zeros((n, 4), dtype=torch.float64, device=dev)
+    nv = net_virial if net_virial is not None else (torch.zeros((6, n), dtype=torch.float64, device=dev) if virials else None)
+    a = _abi.SumNetForceArgs()
+    a.d_net_force, a.d_net_virial, a.net_virial_pitch = ptr(nf), ptr(nv), n
+    for k, f in enumerate(forces):
+        a.force_list.f[k] = f.data_ptr()
+        if virials:
+            a.force_list.v[k] = virials[k].data_ptr()
+            a.force_list.vpitch[k] = n
+    a.nparticles, a.clear, a.compute_virial = n, int(clear), int(bool(virials))
+    check(_abi.lib.hmd_integrator_sum_net_force(C.byref(a), _stream(nf)), "hmd_integrator_sum_net_force")
+    return nf, nv
+
+
+def step_one(pos, vel, accel, image, box, dt, rescale=1.0, group=None, limit=None):
+    a = _abi.StepOneArgs()
+    a.d_pos, a.d_vel, a.d_accel, a.d_image, a.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
+    a.group_size = pos.shape[0] if group is None else group.numel()
+    a.box, a.rescale_factor, a.deltaT = box, float(rescale), float(dt)
+    a.use_limit = int(limit is not None)
+    a.maximum_displacement = float(limit or 0.0)
+    check(_abi.lib.hmd_nvt_rescale_step_one(C.byref(a), _stream(pos)), "hmd_nvt_rescale_step_one")
+
+
+def step_two(vel, accel, net_force, dt, rescale=1.0, group=None):
+    a = _abi.StepTwoArgs()
+    a.d_vel, a.d_accel, a.d_group_members, a.d_net_force = ptr(vel), ptr(accel), ptr(group), ptr(net_force)
+    a.group_size = vel.shape[0] if group is None else group.numel()
+    a.deltaT, a.rescale_factor = float(dt), float(rescale)
+    check(_abi.lib.hmd_nvt_rescale_step_two(C.byref(a), _stream(vel)), "hmd_nvt_rescale_step_two")
+
+
+def compute_accelerations(vel, net_force):
+    accel = torch.zeros((vel.shape[0], 3), dtype=torch.float64, device=vel.device)
+    check(_abi.lib.hmd_compute_accelerations(ptr(accel), ptr(vel), ptr(net_force), vel.shape[0], _stream(vel)),
+          "hmd_compute_accelerations")
+    return accel
+
+
+def thermo(vel, net_force, net_virial=None, group=None):
+    dev = vel.device
+    out = torch.zeros(8, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(_abi.lib.hmd_thermo_scratch_bytes(), dtype=torch.uint8, device=dev)
+    a = _abi.ThermoArgs()
+    a.d_out, a.d_scratch, a.d_vel, a.d_net_force, a.d_net_virial = ptr(out), ptr(scratch), ptr(vel), ptr(net_force), ptr(net_virial)
+    a.net_virial_pitch = vel.shape[0]
+    a.d_group_members = ptr(group)
+    a.group_size = vel.shape[0] if group is None else group.numel()
+    check(_abi.lib.hmd_compute_thermo(C.byref(a), _stream(vel)), "hmd_compute_thermo")
+    return out.cpu().numpy()
+
+
+def cell_order(cl, N):
+    dev = cl["xyzf"].device
+    ncells = cl["cell_size"].numel()
+    order = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+    offs = torch.zeros(ncells + 1, dtype=torch.int32, device=dev)
+    wsb = _abi.lib.hmd_cell_order_workspace_bytes(ncells)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+    a = _abi.CellOrderArgs()
+    a.d_order, a.d_cell_offset, a.d_cell_size, a.d_cell_xyzf = ptr(order), ptr(offs), ptr(cl["cell_size"]), ptr(cl["xyzf"])
+    a.ci = Index3D(*cl["dim"])
+    a.cli = Index2D(cl["Nmax"], ncells)
+    a.N = N
+    a.d_workspace, a.workspace_bytes = ptr(ws), wsb
+    check(_abi.lib.hmd_cell_order(C.byref(a), _stream(order)), "hmd_cell_order")
+    return order, offs
+
+
+def gather_rows(src, order):
+    out = torch.empty_like(src)
+    eb = src.element_size() * (src.shape[1] if src.dim() == 2 else 1)
+    check(_abi.lib.hmd_gather_rows(ptr(out), ptr(src), ptr(order), order.numel(), eb, _stream(src)), "hmd_gather_rows")
+    return out
+
+
+def build_rtag(tag):
+    rtag = torch.zeros_like(tag)
+    check(_abi.lib.hmd_build_rtag(ptr(rtag), ptr(tag), tag.numel(), _stream(tag)), "hmd_build_rtag")
+    return rtag
+
+
+def ghost_plan(pos, N, box, r_ghost, mask):
+    dev = pos.device
+    plan = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+    rg = torch.as_tensor(np.asarray(r_ghost, dtype=np.float64), device=dev)
+    a = _abi.GhostPlanArgs()
+    a.d_plan, a.d_pos, a.N, a.box, a.d_r_ghost, a.ntypes, a.mask = ptr(plan), ptr(pos), N, box, ptr(rg), rg.numel(), mask
+    check(_abi.lib.hmd_make_ghost_exchange_plan(C.byref(a), _stream(pos)), "hmd_make_ghost_exchange_plan")
+    return plan
+
+
+def pack_ghost_positions(pos, send_idx, shift_id, shift_table, out=None):
+    n = send_idx.numel()
+    if out is None:
+        out = torch.empty((n, 4), dtype=torch.float64, device=pos.device)
+    a = _abi.PackPosArgs()
+    a.d_out, a.d_pos, a.d_send_idx, a.d_send_shift_id, a.d_shift_table, a.n_send = ptr(out), ptr(pos), ptr(send_idx), ptr(shift_id), ptr(shift_table), n
+    check(_abi.lib.hmd_pack_ghost_positions(C.byref(a), _stream(pos)), "hmd_pack_ghost_positions")
+    return out

@@ -1,0 +1,454 @@
+/* hoomd_amd.h -- C ABI of the MI355X (gfx950) kernel-driver layer for HOOMD-blue's short-range MD step.
+ *
+ * Each entry point replaces one of the reference's GPU kernel drivers (free functions in
+ * namespace hoomd[::md]::kernel that take raw device pointers); the reference interface it
+ * stands in for is cited as file:line relative to the HOOMD-blue 4.1.0 source tree.
+ *
+ * Conventions
+ *   - every pointer named d_* is device memory owned by the caller; drivers never allocate;
+ *   - Scalar is double: hmd_scalar4 == Scalar4 (32 B), hmd_scalar3 == Scalar3 (24 B);
+ *   - the particle type id is bit-stuffed in the low 32 bits of pos.w (hoomd/HOOMDMath.h:166-217),
+ *     mass travels in vel.w, potential energy in force.w;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream the reference uses);
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     HMD_ERR_* code when the arguments are rejected before anything is launched;
+ *   - launches are asynchronous; overflow / NaN / out-of-box conditions are reported through
+ *     the same small device flag arrays the reference uses and are read by the caller.
+ */
+#ifndef HOOMD_AMD_H
+#define HOOMD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMD_ABI_VERSION 1
+
+#define HMD_OK 0
+#define HMD_ERR_INVALID_ARGUMENT (-1) /* NULL where a pointer is required, zero-sized indexer ... */
+#define HMD_ERR_UNSUPPORTED (-2)      /* valid in the reference, not built here (see message)    */
+#define HMD_ERR_TOO_LARGE (-3)        /* exceeds a documented fixed limit                         */
+
+#define HMD_NO_BODY 0xffffffffu
+
+typedef struct
+    {
+    double x, y, z, w;
+    } hmd_scalar4;
+typedef struct
+    {
+    double x, y, z;
+    } hmd_scalar3;
+typedef struct
+    {
+    int x, y, z;
+    } hmd_int3;
+typedef struct
+    {
+    unsigned int x, y;
+    } hmd_uint2;
+typedef struct
+    {
+    unsigned int x, y, z;
+    } hmd_uint3;
+
+/* BoxDim (hoomd/BoxDim.h:633-641) as plain data.  nearest_plane holds
+   BoxDim::getNearestPlaneDistance() (hoomd/BoxDim.h:536-552) evaluated once on the host so that
+   host and device bin with the identical value. */
+typedef struct
+    {
+    double lo[3];
+    double hi[3];
+    double L[3];
+    double Linv[3];
+    double xy, xz, yz;
+    double nearest_plane[3];
+    unsigned char periodic[3];
+    unsigned char pad_[5];
+    } hmd_box_t;
+
+/* Index2D / Index3D (hoomd/Index1D.h:32-89, :95-165): (i,j) -> j*w+i ; (i,j,k) -> (k*h+j)*w+i */
+typedef struct
+    {
+    unsigned int w, h;
+    } hmd_index2d_t;
+typedef struct
+    {
+    unsigned int w, h, d;
+    } hmd_index3d_t;
+
+/* Fills every field of *box from lengths + tilt factors (hoomd/BoxDim.h:125-130,174-187). Host only. */
+void hmd_box_init(hmd_box_t* box, double Lx, double Ly, double Lz, double xy, double xz, double yz);
+/* As BoxDim::setLoHi (hoomd/BoxDim.h:209-221); tilt factors are kept. Host only. */
+void hmd_box_set_lo_hi(hmd_box_t* box, const double lo[3], const double hi[3]);
+
+int hmd_abi_version(void);
+/* Text for the last negative return code on this host thread. */
+const char* hmd_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Cell list.  Replaces gpu_compute_cell_list (hoomd/CellListGPU.cuh:23-44, hoomd/CellListGPU.cu:173-244).
+ * The caller zeroes d_cell_size first (hoomd/CellListGPU.cc:96-99) unless clear_cell_size != 0.
+ * d_xyzf / d_type_body / d_cell_idx / d_cell_orientation may be NULL to skip that output.
+ * xyzf.w receives the charge (flag_charge), the type (flag_type) or else the particle index.
+ * d_conditions: x = 1 + largest overflowing slot, y = 1 + index of a NaN particle,
+ *               z = 1 + index of an owned particle outside the box (hoomd/CellList.cc:549-607).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+    {
+    unsigned int* d_cell_size;
+    hmd_scalar4* d_xyzf;
+    hmd_uint2* d_type_body;
+    hmd_scalar4* d_cell_orientation;
+    unsigned int* d_cell_idx;
+    hmd_uint3* d_conditions;
+    const hmd_scalar4* d_pos;
+    const hmd_scalar4* d_orientation;
+    const double* d_charge;
+    const double* d_diameter;
+    const unsigned int* d_body;
+    unsigned int N;
+    unsigned int n_ghost;
+    unsigned int Nmax;
+    int flag_charge;
+    int flag_type;
+    hmd_box_t box;
+    hmd_index3d_t ci;
+    hmd_index2d_t cli;
+    hmd_scalar3 ghost_width;
+    unsigned int block_size; /* 0 = library default */
+    int clear_cell_size;     /* non-zero: zero d_cell_size on `stream` before binning */
+    } hmd_cell_list_args_t;
+int hmd_compute_cell_list(const hmd_cell_list_args_t* args, void* stream);
+
+/* Deterministic mode: orders the members of every cell by particle index.
+   Replaces gpu_sort_cell_list (hoomd/CellListGPU.cuh:64-76, hoomd/CellListGPU.cu:478-565);
+   done per cell in LDS instead of a global key sort, so no temporaries are needed.
+   Cells holding more than 1024 members are rejected with HMD_ERR_TOO_LARGE. */
+typedef struct
+    {
+    const unsigned int* d_cell_size;
+    hmd_scalar4* d_xyzf;
+    hmd_uint2* d_type_body;
+    unsigned int* d_cell_idx; /* optional */
+    hmd_index3d_t ci;
+    hmd_index2d_t cli;
+    int flag_is_index; /* xyzf.w holds the particle index (sort key); otherwise d_cell_idx is required */
+    } hmd_sort_cell_list_args_t;
+int hmd_sort_cell_list(const hmd_sort_cell_list_args_t* args, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Neighbor list.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces gpu_nlist_needs_update_check_new (hoomd/md/NeighborListGPU.cu:86-128): sets
+   *d_result = checkn (atomic max) when any of the N particles moved at least
+   ((rcut_max[type]+r_buff)*lambda_min - rcut_max[type])/2 from lambda*last_pos (minimum image). */
+typedef struct
+    {
+    unsigned int* d_result;
+    const hmd_scalar4* d_last_pos;
+    const hmd_scalar4* d_pos;
+    unsigned int N;
+    hmd_box_t box;
+    const double* d_rcut_max;
+    double r_buff;
+    unsigned int ntypes;
+    double lambda_min;
+    hmd_scalar3 lambda;
+    unsigned int checkn;
+    } hmd_nlist_check_args_t;
+int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream);
+
+/* Replaces gpu_nlist_build_head_list (hoomd/md/NeighborListGPU.cu:415-456):
+   d_head_list[i] = sum_{j<i} d_Nmax[type_j];  *d_req_size_nlist = sum over all N.
+   d_workspace must hold hmd_nlist_head_list_workspace_bytes(N) bytes. */
+size_t hmd_nlist_head_list_workspace_bytes(unsigned int N);
+typedef struct
+    {
+    size_t* d_head_list;
+    size_t* d_req_size_nlist;
+    const unsigned int* d_Nmax;
+    const hmd_scalar4* d_pos;
+    unsigned int N;
+    unsigned int ntypes;
+    void* d_workspace;
+    size_t workspace_bytes;
+    } hmd_head_list_args_t;
+int hmd_nlist_build_head_list(const hmd_head_list_args_t* args, void* stream);
+
+/* Replaces gpu_compute_nlist_binned (hoomd/md/NeighborListGPUBinned.cuh:35-62,
+   hoomd/md/NeighborListGPUBinned.cu:756-823).  Full neighbor list only (as the reference's GPU
+   class, hoomd/md/NeighborListGPUBinned.cc:51-54).  For every owned particle i: all j != i in the
+   adjacent cells with r_cut(ti,tj) > 0 and |minImage(ri-rj)|^2 <= (r_cut(ti,tj)+r_buff)^2, in
+   unspecified order, at d_nlist[d_head_list[i] + k]; d_n_neigh[i] counts all hits, even those
+   beyond d_Nmax[ti], and then d_conditions[ti] = max(.., n_neigh) signals the overflow.
+   d_last_updated_pos[i] = pos[i].  d_cell_xyzf.w must hold particle indices and
+   d_cell_type_body the (type, body) pairs written by hmd_compute_cell_list.
+   threads_per_particle and block_size are accepted for interface parity; 0 = library default. */
+typedef struct
+    {
+    unsigned int* d_nlist;
+    unsigned int* d_n_neigh;
+    hmd_scalar4* d_last_updated_pos;
+    unsigned int* d_conditions;
+    const unsigned int* d_Nmax;
+    const size_t* d_head_list;
+    const hmd_scalar4* d_pos;
+    const unsigned int* d_body;
+    unsigned int N;
+    const unsigned int* d_cell_size;
+    const hmd_scalar4* d_cell_xyzf;
+    const unsigned int* d_cell_idx; /* unused: xyzf carries the index */
+    const hmd_uint2* d_cell_type_body;
+    const unsigned int* d_cell_adj;
+    hmd_index3d_t ci;
+    hmd_index2d_t cli;
+    hmd_index2d_t cadji;
+    hmd_box_t box;
+    const double* d_r_cut;
+    double r_buff;
+    unsigned int ntypes;
+    unsigned int threads_per_particle;
+    unsigned int block_size;
+    int filter_body;
+    hmd_scalar3 ghost_width;
+    } hmd_nlist_binned_args_t;
+int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, void* stream);
+
+/* Replaces gpu_nlist_filter (hoomd/md/NeighborListGPU.cu:225-267): removes from every row the
+   entries found in that particle's exclusion list d_ex_list[exli(idx, k)], k < d_n_ex[idx]. */
+typedef struct
+    {
+    unsigned int* d_n_neigh;
+    unsigned int* d_nlist;
+    const size_t* d_head_list;
+    const unsigned int* d_n_ex;
+    const unsigned int* d_ex_list;
+    hmd_index2d_t exli;
+    unsigned int N;
+    unsigned int block_size;
+    } hmd_nlist_filter_args_t;
+int hmd_nlist_filter(const hmd_nlist_filter_args_t* args, void* stream);
+
+/* Replaces gpu_update_exclusion_list (hoomd/md/NeighborListGPU.cu:312-340). */
+typedef struct
+    {
+    const unsigned int* d_tag;
+    const unsigned int* d_rtag;
+    const unsigned int* d_n_ex_tag;
+    const unsigned int* d_ex_list_tag;
+    hmd_index2d_t ex_list_tag_indexer;
+    unsigned int* d_n_ex_idx;
+    unsigned int* d_ex_list_idx;
+    hmd_index2d_t ex_list_indexer;
+    unsigned int N;
+    } hmd_update_exclusion_args_t;
+int hmd_update_exclusion_list(const hmd_update_exclusion_args_t* args, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Pair forces.  Replaces gpu_compute_pair_forces<evaluator>(const pair_args_t&, const param_type*)
+ * (hoomd/md/PotentialPairGPU.cuh:44-98 for the argument block, :579-656 for the driver); one
+ * exported symbol per evaluator, as the reference instantiates one driver per evaluator
+ * (hoomd/md/CMakeLists.txt:498-547, example_plugins/pair_plugin/PotentialPairExampleGPUKernel.cu:13-15).
+ * shift_mode: 0 none, 1 shift, 2 xplor (hoomd/md/PotentialPair.h:126-131).
+ * d_force[i] = (F_i, sum_j E_ij/2); d_virial[c*virial_pitch+i], c = xx,xy,xz,yy,yz,zz, only when
+ * compute_virial != 0.  Rows of owned particles only; ghost indices may appear as neighbors.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+    {
+    hmd_scalar4* d_force;
+    double* d_virial;
+    size_t virial_pitch;
+    unsigned int N;
+    unsigned int n_max;
+    const hmd_scalar4* d_pos;
+    const double* d_charge;
+    hmd_box_t box;
+    const unsigned int* d_n_neigh;
+    const unsigned int* d_nlist;
+    const size_t* d_head_list;
+    const double* d_rcutsq;
+    const double* d_ronsq;
+    size_t size_neigh_list;
+    unsigned int ntypes;
+    unsigned int block_size;           /* 0 = library default */
+    unsigned int shift_mode;
+    unsigned int compute_virial;
+    unsigned int threads_per_particle; /* power of two in [1,64]; 0 = library default */
+    } hmd_pair_args_t;
+
+/* EvaluatorPairLJ::param_type (hoomd/md/EvaluatorPairLJ.h:99-155) */
+typedef struct
+    {
+    double sigma_6;
+    double epsilon_x_4;
+    } hmd_lj_params_t;
+/* EvaluatorPairExample::param_type (example_plugins/pair_plugin/EvaluatorPairExample.h:37-76) */
+typedef struct
+    {
+    double k;
+    double sigma;
+    } hmd_example_params_t;
+
+int hmd_compute_pair_forces_lj(const hmd_pair_args_t* args, const hmd_lj_params_t* d_params, void* stream);
+int hmd_compute_pair_forces_example(const hmd_pair_args_t* args, const hmd_example_params_t* d_params, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Integrator.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces gpu_integrator_sum_net_force (hoomd/Integrator.cu:171-230, force list struct
+   hoomd/Integrator.cuh:23-77): net = (clear ? 0 : net) + sum of up to 6 force computes over
+   nparticles (owned + ghosts).  Torque pointers (net and per force) may be NULL: point particles. */
+typedef struct
+    {
+    const hmd_scalar4* f[6];
+    const hmd_scalar4* t[6];
+    const double* v[6];
+    size_t vpitch[6];
+    } hmd_force_list_t;
+typedef struct
+    {
+    hmd_scalar4* d_net_force;
+    double* d_net_virial;
+    size_t net_virial_pitch;
+    hmd_scalar4* d_net_torque;
+    hmd_force_list_t force_list;
+    unsigned int nparticles;
+    int clear;
+    int compute_virial;
+    } hmd_sum_net_force_args_t;
+int hmd_integrator_sum_net_force(const hmd_sum_net_force_args_t* args, void* stream);
+
+/* Replaces gpu_nvt_rescale_step_one (hoomd/md/TwoStepConstantVolumeGPU.cu:102-155):
+   v += a*dt/2 ; v *= rescale_factor ; x += v*dt ; wrap(x, image), for the group members.
+   d_group_members may be NULL for the identity group 0..group_size-1.
+   The displacement limit follows the CPU class (hoomd/md/TwoStepConstantVolume.cc:45-53). */
+typedef struct
+    {
+    hmd_scalar4* d_pos;
+    hmd_scalar4* d_vel;
+    const hmd_scalar3* d_accel;
+    hmd_int3* d_image;
+    const unsigned int* d_group_members;
+    unsigned int group_size;
+    hmd_box_t box;
+    unsigned int block_size;
+    double rescale_factor;
+    double deltaT;
+    int use_limit;
+    double maximum_displacement;
+    } hmd_step_one_args_t;
+int hmd_nvt_rescale_step_one(const hmd_step_one_args_t* args, void* stream);
+
+/* Replaces gpu_nvt_rescale_step_two (hoomd/md/TwoStepConstantVolumeGPU.cu:215-260):
+   a = F * (1/m) ; v *= rescale_factor ; v += a*dt/2 (CPU-class arithmetic,
+   hoomd/md/TwoStepConstantVolume.cc:243-252). */
+typedef struct
+    {
+    hmd_scalar4* d_vel;
+    hmd_scalar3* d_accel;
+    const unsigned int* d_group_members;
+    unsigned int group_size;
+    const hmd_scalar4* d_net_force;
+    unsigned int block_size;
+    double deltaT;
+    double rescale_factor;
+    } hmd_step_two_args_t;
+int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
+
+/* a = F/m for all N particles: Integrator::computeAccelerations (hoomd/Integrator.cc:106-127),
+   which the reference runs on the host; here it stays on the device. */
+int hmd_compute_accelerations(hmd_scalar3* d_accel,
+                              const hmd_scalar4* d_vel,
+                              const hmd_scalar4* d_net_force,
+                              unsigned int N,
+                              void* stream);
+
+/* Kinetic energy, potential energy and the virial trace of a group, reduced on the device.
+   Replaces gpu_compute_thermo_partial + gpu_compute_thermo_final
+   (hoomd/md/ComputeThermoGPU.cu:46-130,326-520).  d_out[0] = sum m v^2 / 2, d_out[1] = sum
+   net_force.w, d_out[2] = sum (virial xx+yy+zz) (0 when d_net_virial is NULL), d_out[3..5] = total
+   momentum.  d_scratch needs hmd_thermo_scratch_bytes() bytes; d_out 8 doubles. */
+size_t hmd_thermo_scratch_bytes(void);
+typedef struct
+    {
+    double* d_out;
+    void* d_scratch;
+    const hmd_scalar4* d_vel;
+    const hmd_scalar4* d_net_force;
+    const double* d_net_virial;
+    size_t net_virial_pitch;
+    const unsigned int* d_group_members; /* NULL = identity */
+    unsigned int group_size;
+    } hmd_thermo_args_t;
+int hmd_compute_thermo(const hmd_thermo_args_t* args, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Particle reordering by cell (data locality for the neighbor gathers).  Stands in for the
+ * reference's space-filling-curve sorter kernels gpu_sfc_bin_particles / gpu_apply_sorted_order
+ * (hoomd/SFCPackTunerGPU.cu:26-160): d_order[k] = old index of the particle that becomes index k,
+ * taken from a cell list (cells walked in memory order, members in slot order).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+    {
+    unsigned int* d_order;         /* out: N entries */
+    unsigned int* d_cell_offset;   /* scratch: ncells+1 entries */
+    const unsigned int* d_cell_size;
+    const hmd_scalar4* d_cell_xyzf; /* w = particle index */
+    hmd_index3d_t ci;
+    hmd_index2d_t cli;
+    unsigned int N;                /* owned particles; entries with index >= N are skipped */
+    void* d_workspace;
+    size_t workspace_bytes;        /* >= hmd_cell_order_workspace_bytes(ncells) */
+    } hmd_cell_order_args_t;
+size_t hmd_cell_order_workspace_bytes(unsigned int ncells);
+int hmd_cell_order(const hmd_cell_order_args_t* args, void* stream);
+
+/* out[k] = in[d_order[k]] for arrays of elem_bytes-sized elements (4, 8, 12, 16, 24 or 32). */
+int hmd_gather_rows(void* d_out, const void* d_in, const unsigned int* d_order, unsigned int N,
+                    unsigned int elem_bytes, void* stream);
+/* d_rtag[d_tag[k]] = k */
+int hmd_build_rtag(unsigned int* d_rtag, const unsigned int* d_tag, unsigned int N, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Halo exchange helpers (the CommunicatorGPU role, hoomd/CommunicatorGPU.cu).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Ghost plan: bit d of d_plan[i] is set when owned particle i lies within r_ghost of face d of
+   the local box (0:+x 1:-x 2:+y 3:-y 4:+z 5:-z), only in decomposed directions.
+   Replaces gpu_make_ghost_exchange_plan (hoomd/CommunicatorGPU.cu:306-372). */
+typedef struct
+    {
+    unsigned int* d_plan;
+    const hmd_scalar4* d_pos;
+    unsigned int N;
+    hmd_box_t box;             /* local box */
+    const double* d_r_ghost;   /* per type */
+    unsigned int ntypes;
+    unsigned int mask;         /* bit d set: direction d has a neighbouring domain */
+    } hmd_ghost_plan_args_t;
+int hmd_make_ghost_exchange_plan(const hmd_ghost_plan_args_t* args, void* stream);
+
+/* out[k] = pos[d_send_idx[k]] + shift[d_send_shift_id[k]] (shift table of 27 periodic image
+   vectors; id 13 = no shift).  Replaces gpu_pack_wrap_kernel / gpu_pack_kernel
+   (hoomd/CommunicatorGPU.cu:778-875) for the position field. */
+typedef struct
+    {
+    hmd_scalar4* d_out;
+    const hmd_scalar4* d_pos;
+    const unsigned int* d_send_idx;
+    const unsigned char* d_send_shift_id;
+    const hmd_scalar3* d_shift_table; /* 27 entries */
+    unsigned int n_send;
+    } hmd_pack_pos_args_t;
+int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOOMD_AMD_H */

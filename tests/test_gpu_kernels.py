@@ -1,0 +1,565 @@
+"""GPU parity tests: every HIP driver, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bit-exact for cell membership, neighbor sets, head lists, flags and the
+integrator half steps; forces/virials within 1e-6 relative (asserted much tighter)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+F_RTOL = 1e-6  # tolerance the project states for forces and virials
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X: torch.cuda.is_available() is False")
+    from hoomd_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def A():
+    from hoomd_amd import _abi
+    return _abi
+
+
+def liquid(n, rho=0.84, jitter=0.12, seed=5, ntypes=1):
+    a = (1.0 / rho) ** (1.0 / 3.0)
+    L = n * a
+    g = (np.arange(n) + 0.5) * a - L / 2
+    xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(seed)
+    xyz = xyz + rng.normal(0, jitter, xyz.shape)
+    xyz = (xyz + L / 2) % L - L / 2
+    typ = rng.integers(0, ntypes, len(xyz)) if ntypes > 1 else np.zeros(len(xyz), dtype=int)
+    return xyz, typ, L
+
+
+def boxes(A, L, **kw):
+    if np.isscalar(L):
+        L = (L, L, L)
+    return A.Box.from_L(*L, **kw), orc.Box.from_L(*L, **kw)
+
+
+def cell_sets(cell_size, xyzf):
+    """per cell: sorted tuple of (index, x, y, z) -- order independent and bit exact"""
+    out = []
+    for c in range(len(cell_size)):
+        sz = int(cell_size[c])
+        idx = orc.unpack_int_w(xyzf[c, :sz, 3])
+        rows = sorted((int(i), *map(float, xyzf[c, s, :3])) for s, i in enumerate(idx))
+        out.append(tuple(rows))
+    return out
+
+
+def gpu_nlist(K, A, pos_t, N, gbox, obox, r_cut, r_buff, n_ghost=0, ghost_width=(0, 0, 0), body=None, filter_body=False,
+              ndim=3):
+    _, _, rmax, _ = orc.update_rlist(np.asarray(r_cut, dtype=float), r_buff)
+    dim = orc.cell_dimensions(obox, rmax + r_buff, 1, ghost_width, ndim)
+    body_t = torch.as_tensor(np.asarray(body, dtype=np.int64).astype(np.uint32).view(np.int32), device="cuda") if body is not None else None
+    cl = K.cell_list_auto(pos_t, N, n_ghost, gbox, dim, ghost_width, body=body_t)
+    adj = torch.as_tensor(orc.cell_adj(dim, 1, ndim).view(np.int32), device="cuda")
+    nl = K.nlist_binned(pos_t, N, gbox, r_cut, r_buff, cl, adj, n_ghost, ghost_width, body=body_t, filter_body=filter_body)
+    return nl, cl, dim
+
+
+def sets_of(nl, N):
+    return orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                             nl["head"].cpu().numpy().view(np.uint64)[:N])
+
+
+# ------------------------------------------------------------------ cell list
+@pytest.mark.parametrize("L,width,gw", [((20.0, 31.0, 17.5), 3.0, (0, 0, 0)), ((12.0, 12.0, 12.0), 2.9, (0, 0, 0)),
+                                        ((16.0, 9.0, 11.0), 2.0, (1.5, 0, 1.5))])
+def test_cell_list_matches_oracle_bit_exact(K, A, L, width, gw):
+    rng = np.random.default_rng(17)
+    N, n_ghost = 9000, (700 if any(gw) else 0)
+    xyz = (rng.random((N, 3)) - 0.5) * np.array(L)
+    periodic = tuple(0 if g else 1 for g in gw)
+    if n_ghost:
+        gx = (rng.random((n_ghost, 3)) - 0.5) * (np.array(L) + 2 * np.array(gw) * 1.05)  # some fall outside
+        xyz = np.concatenate([xyz, gx])
+    typ = rng.integers(0, 3, len(xyz))
+    gbox, obox = boxes(A, L, periodic=periodic)
+    dim = orc.cell_dimensions(obox, width, 1, gw)
+    pos = orc.pack_pos(xyz, typ)
+    ref = orc.cell_list_auto(pos, N, n_ghost, obox, dim, gw, want_type_body=True)
+    got = K.cell_list_auto(torch.from_numpy(pos).cuda(), N, n_ghost, gbox, dim, gw, want_idx=True)
+    assert got["Nmax"] == ref["Nmax"]
+    cs = got["cell_size"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(cs, ref["cell_size"])
+    assert cell_sets(cs, got["xyzf"].cpu().numpy()) == cell_sets(ref["cell_size"], ref["xyzf"])
+    assert got["conditions"].cpu().numpy().tolist() == [0, 0, 0]
+    # type_body and idx travel with the same slot
+    xyzf = got["xyzf"].cpu().numpy()
+    tb = got["type_body"].cpu().numpy().view(np.uint32)
+    idx = got["idx"].cpu().numpy().view(np.uint32)
+    for c in range(0, len(cs), 7):
+        for s in range(cs[c]):
+            i = int(orc.unpack_int_w(xyzf[c, s:s + 1, 3])[0])
+            assert idx[c, s] == i and tb[c, s, 0] == typ[i] and tb[c, s, 1] == orc.NO_BODY
+
+
+def test_cell_list_overflow_nan_and_out_of_box_flags(K, A):
+    gbox, obox = boxes(A, 10.0)
+    dim = orc.cell_dimensions(obox, 2.0)
+    xyz = np.zeros((40, 3))
+    xyz[:, 0] = np.linspace(-0.4, 0.4, 40)  # all in one cell
+    pos = torch.from_numpy(orc.pack_pos(xyz, np.zeros(40, int))).cuda()
+    r = K.compute_cell_list(pos, 40, 0, gbox, dim, 8)
+    assert r["conditions"].cpu().numpy().tolist() == [40, 0, 0]
+    assert int(r["cell_size"].sum()) == 40
+    bad = orc.pack_pos([[0, 0, 0], [np.nan, 0, 0], [0, 6.0, 0]], [0, 0, 0])
+    r = K.compute_cell_list(torch.from_numpy(bad).cuda(), 3, 0, gbox, dim, 4)
+    assert r["conditions"].cpu().numpy().tolist() == [0, 2, 3]
+    # an out-of-box ghost is ignored silently
+    r = K.compute_cell_list(torch.from_numpy(bad[[0, 2]]).cuda(), 1, 1, gbox, dim, 4)
+    assert r["conditions"].cpu().numpy().tolist() == [0, 0, 0] and int(r["cell_size"].sum()) == 1
+
+
+def test_cell_list_flag_modes_and_reference_small_case(K, A):
+    with open(os.path.join(G, "reference_cases.json")) as f:
+        c = json.load(f)["cell_small"]
+    gbox, obox = boxes(A, c["L"])
+    dim = orc.cell_dimensions(obox, c["width"])
+    assert list(dim) == c["dim"]
+    pos = torch.from_numpy(orc.pack_pos(c["pos"], c["type"])).cuda()
+    charge = torch.tensor(c["charge"], dtype=torch.float64).cuda()
+    body = torch.tensor(c["body"], dtype=torch.int32).cuda()
+    r = K.cell_list_auto(pos, 8, 0, gbox, dim, flag_charge=True, charge=charge, body=body)
+    cs = r["cell_size"].cpu().numpy()
+    xyzf = r["xyzf"].cpu().numpy()
+    tb = r["type_body"].cpu().numpy()
+    for cell in c["cells"]:
+        ci = orc.index3d(dim[0], dim[1], *cell["cell"])
+        assert cs[ci] == len(cell["members"])
+        for s in range(cs[ci]):
+            m = c["charge"].index(xyzf[ci, s, 3])
+            assert m in cell["members"] and tb[ci, s].tolist() == [c["type"][m], c["body"][m]]
+    r = K.cell_list_auto(pos, 8, 0, gbox, dim, flag_type=True)
+    xyzf = r["xyzf"].cpu().numpy()
+    ci = orc.index3d(dim[0], dim[1], 2, 2, 3)
+    assert orc.unpack_int_w(xyzf[ci, :1, 3])[0] == 2  # type of particle 1
+
+
+def test_sort_cell_list_orders_members_by_index(K, A):
+    xyz, typ, L = liquid(14, seed=2)
+    gbox, obox = boxes(A, L)
+    dim = orc.cell_dimensions(obox, 2.9)
+    N = len(xyz)
+    perm = np.random.default_rng(0).permutation(N)
+    pos = torch.from_numpy(orc.pack_pos(xyz[perm], typ)).cuda()
+    cl = K.cell_list_auto(pos, N, 0, gbox, dim, want_idx=True)
+    before = cell_sets(cl["cell_size"].cpu().numpy().view(np.uint32), cl["xyzf"].cpu().numpy())
+    K.sort_cell_list(cl)
+    cs = cl["cell_size"].cpu().numpy().view(np.uint32)
+    xyzf = cl["xyzf"].cpu().numpy()
+    assert cell_sets(cs, xyzf) == before
+    idx = cl["idx"].cpu().numpy().view(np.uint32)
+    for c in range(len(cs)):
+        members = orc.unpack_int_w(xyzf[c, :cs[c], 3])
+        assert np.all(np.diff(members.astype(np.int64)) > 0)
+        assert np.array_equal(idx[c, :cs[c]], members)
+
+
+# ------------------------------------------------------------------ neighbor list
+def test_head_list_matches_oracle(K):
+    rng = np.random.default_rng(1)
+    for N, nt in [(1, 1), (777, 1), (5000, 3), (70000, 4)]:
+        typ = rng.integers(0, nt, N)
+        pos = orc.pack_pos(rng.random((N, 3)), typ)
+        Nmax = rng.integers(1, 9, nt).astype(np.uint32) * 4
+        head_ref, total_ref = orc.build_head_list(pos, N, Nmax)
+        head, total = K.build_head_list(torch.from_numpy(pos).cuda(), N, torch.as_tensor(Nmax.view(np.int32)).cuda())
+        assert total == total_ref
+        assert np.array_equal(head.cpu().numpy().view(np.uint64)[:N], head_ref)
+
+
+def test_nlist_reference_hand_built_cases(K, A):
+    with open(os.path.join(G, "reference_cases.json")) as f:
+        cases = json.load(f)["nlist"]
+    for c in cases:
+        if c["mode"] != "full":
+            continue  # the GPU class builds full lists only (hoomd/md/NeighborListGPUBinned.cc:51-54)
+        gbox, obox = boxes(A, c["L"])
+        n = len(c["pos"])
+        pos = torch.from_numpy(orc.pack_pos(c["pos"], c["type"])).cuda()
+        nl, _, _ = gpu_nlist(K, A, pos, n, gbox, obox, c["r_cut"], c["r_buff"])
+        sets = sets_of(nl, n)
+        if "neighbors" in c:
+            for i, want in enumerate(c["neighbors"]):
+                if want is not None:
+                    assert sets[i].tolist() == want, (c["name"], i)
+        if "n_neigh" in c:
+            assert nl["n_neigh"].cpu().numpy()[:n].tolist() == c["n_neigh"], c["name"]
+
+
+def test_nlist_true_pair_list(K, A):
+    with open(os.path.join(G, "true_pair_list.json")) as f:
+        truth = {tuple(sorted(p)) for p in json.load(f)}
+    g = (np.arange(-3.5, 3.5) + 0.5)
+    xyz = np.stack([m.ravel() for m in np.meshgrid(g, g, g)], 1)
+    gbox, obox = boxes(A, 7.0)
+    pos = torch.from_numpy(orc.pack_pos(xyz, np.zeros(343, int))).cuda()
+    nl, _, _ = gpu_nlist(K, A, pos, 343, gbox, obox, [[1.1]], 0.0)
+    pairs = set()
+    for i, s in enumerate(sets_of(nl, 343)):
+        assert len(s) == 6
+        for j in s:
+            pairs.add(tuple(sorted((i, int(j)))))
+    assert pairs == truth
+
+
+@pytest.mark.parametrize("n,ntypes", [(12, 1), (16, 2), (40, 1)])
+def test_nlist_sets_match_oracle_bit_exact(K, A, n, ntypes):
+    xyz, typ, L = liquid(n, ntypes=ntypes)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, -1.0]]
+    pos = orc.pack_pos(xyz, typ)
+    ref = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=True)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, r_cut, 0.4)
+    assert np.array_equal(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"])
+    assert np.array_equal(nl["Nmax"].cpu().numpy().view(np.uint32), ref["Nmax"])
+    got = sets_of(nl, N)
+    want = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    for i in range(N):
+        assert np.array_equal(got[i], want[i]), i
+    lp = nl["last_pos"].cpu().numpy()
+    assert np.array_equal(lp[:N, :3], pos[:, :3])
+
+
+def test_nlist_triclinic_and_2d_and_body_filter(K, A):
+    rng = np.random.default_rng(9)
+    # triclinic
+    L, tilt = (14.0, 12.0, 13.0), dict(xy=0.2, xz=-0.1, yz=0.15)
+    gbox, obox = A.Box.from_L(*L, **tilt), orc.Box.from_L(*L, **tilt)
+    N = 1500
+    f = rng.random((N, 3)) - 0.5
+    xyz = np.stack([f[:, 0] * L[0] + tilt["xy"] * f[:, 1] * L[1] + tilt["xz"] * f[:, 2] * L[2],
+                    f[:, 1] * L[1] + tilt["yz"] * f[:, 2] * L[2], f[:, 2] * L[2]], 1)
+    pos = orc.pack_pos(xyz, np.zeros(N, int))
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.3, storage_full=True)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[2.0]], 0.3)
+    got, want = sets_of(nl, N), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # 2D box (Lz = 0): hoomd/md/test/test_neighborlist.cc:1347-1518
+    gbox, obox = A.Box.from_L(20.0, 20.0, 0.0), orc.Box.from_L(20.0, 20.0, 0.0)
+    xyz = np.concatenate([(rng.random((800, 2)) - 0.5) * 20.0, np.zeros((800, 1))], 1)
+    pos = orc.pack_pos(xyz, np.zeros(800, int))
+    ref = orc.nlist_binned(pos, 800, obox, [[1.5]], 0.2, storage_full=True, ndim=2)
+    nl, _, dim = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), 800, gbox, obox, [[1.5]], 0.2, ndim=2)
+    assert dim[2] == 1
+    got, want = sets_of(nl, 800), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # body filter: hoomd/md/test/test_neighborlist.cc:942-1057
+    xyz, typ, L = liquid(8, seed=4)
+    N = len(xyz)
+    body = np.where(rng.random(N) < 0.5, rng.integers(0, 20, N), orc.NO_BODY).astype(np.int64)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.3, storage_full=True, body=body, filter_body=True)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[2.0]], 0.3, body=body, filter_body=True)
+    got, want = sets_of(nl, N), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert sum(len(s) for s in got) < sum(len(s) for s in sets_of(gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[2.0]], 0.3)[0], N))
+
+
+def test_nlist_with_ghost_layer_non_periodic_box(K, A):
+    """Local box of a decomposed run: non-periodic in x, ghosts (index >= N) in the padded cells."""
+    rng = np.random.default_rng(21)
+    L = (12.0, 13.0, 14.0)
+    gw = (2.4, 0.0, 0.0)
+    N, ng = 1800, 700
+    own = (rng.random((N, 3)) - 0.5) * np.array(L)
+    gh = (rng.random((ng, 3)) - 0.5) * np.array(L)
+    gh[:, 0] = np.where(rng.random(ng) < 0.5, L[0] / 2 + rng.random(ng) * gw[0], -L[0] / 2 - rng.random(ng) * gw[0])
+    xyz = np.concatenate([own, gh])
+    gbox, obox = boxes(A, L, periodic=(0, 1, 1))
+    pos = orc.pack_pos(xyz, np.zeros(len(xyz), int))
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.4, storage_full=True, n_ghost=ng, ghost_width=gw)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[2.0]], 0.4, n_ghost=ng, ghost_width=gw)
+    got, want = sets_of(nl, N), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert max(int(s.max()) for s in got if len(s)) >= N  # ghosts do appear as neighbors
+
+
+def test_nlist_dense_cell_multiple_candidate_passes(K, A):
+    """More than 768 candidates around one cell and more than 64 particles in it."""
+    rng = np.random.default_rng(2)
+    N = 1400
+    xyz = (rng.random((N, 3)) - 0.5) * 1.8  # one clump
+    gbox, obox = boxes(A, 12.0)
+    pos = orc.pack_pos(xyz, np.zeros(N, int))
+    ref = orc.nlist_binned(pos, N, obox, [[1.0]], 0.2, storage_full=True)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[1.0]], 0.2)
+    got, want = sets_of(nl, N), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_distance_check_matches_oracle(K, A):
+    xyz, typ, L = liquid(12, ntypes=2, seed=8)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    rcm = [2.5, 2.0]
+    rng = np.random.default_rng(0)
+    for scale, lam in [(0.05, (1, 1, 1)), (0.11, (1, 1, 1)), (0.124, (1, 1, 1)), (0.05, (0.99, 1.0, 1.01))]:
+        d = rng.normal(0, 1, (N, 3))
+        d *= scale / np.linalg.norm(d, axis=1)[:, None] * rng.random((N, 1))
+        cur = pos.copy()
+        cur[:, :3] += d
+        want = orc.distance_check(cur, pos, N, obox, rcm, 0.25, lam)
+        got = K.nlist_check(torch.from_numpy(cur).cuda(), torch.from_numpy(pos).cuda(), N, gbox, rcm, 0.25, lam, checkn=7)
+        assert got == (7 if want else 0)
+    # a particle that crossed the periodic boundary did not "move" a box length
+    cur = pos.copy()
+    cur[0, 0] = L / 2 - 1e-3
+    last = pos.copy()
+    last[0, 0] = -L / 2 + 1e-3
+    assert K.nlist_check(torch.from_numpy(cur).cuda(), torch.from_numpy(last).cuda(), N, gbox, rcm, 0.25) == 0
+
+
+def test_exclusion_filter_matches_oracle(K, A):
+    xyz, typ, L = liquid(9, seed=6)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    nl, _, _ = gpu_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, [[2.5]], 0.4)
+    n_neigh = nl["n_neigh"].cpu().numpy().view(np.uint32)[:N].copy()
+    nlist = nl["nlist"].cpu().numpy().view(np.uint32).copy()
+    head = nl["head"].cpu().numpy().view(np.uint64)[:N].copy()
+    # exclusions (i,i+1),(i,i+2) as hoomd/md/test/test_neighborlist.cc:1070-1090
+    n_ex = np.zeros(N, dtype=np.uint32)
+    ex = np.zeros((4, N), dtype=np.uint32)
+    for i in range(N):
+        for j in (i + 1, i + 2):
+            if j < N:
+                for a_, b_ in ((i, j), (j, i)):
+                    ex[n_ex[a_], a_] = b_
+                    n_ex[a_] += 1
+    K.nlist_filter(N, nl["head"], torch.from_numpy(n_ex.view(np.int32)).cuda(), torch.from_numpy(ex.view(np.int32)).cuda(),
+                   nl["n_neigh"], nl["nlist"])
+    orc.nlist_filter(N, head, n_ex, ex, n_neigh, nlist)
+    assert np.array_equal(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], n_neigh)
+    got = sets_of(nl, N)
+    want = orc.neighbor_sets(n_neigh, nlist, head)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert all((i + 1) not in s and (i + 2) not in s for i, s in enumerate(got))
+
+
+# ------------------------------------------------------------------ pair forces
+def _rel_err(a, b):
+    scale = np.maximum(np.abs(b), 1e-300)
+    return np.max(np.abs(a - b) / np.maximum(scale, np.abs(b).max() * 1e-9))
+
+
+@pytest.mark.parametrize("shift_mode", [0, 1, 2])
+@pytest.mark.parametrize("ntypes", [1, 2])
+def test_lj_forces_match_oracle(K, A, shift_mode, ntypes):
+    xyz, typ, L = liquid(14, ntypes=ntypes, seed=3 + ntypes)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    if ntypes == 1:
+        r_cut, params = [[2.5]], [orc.lj_params(1.0, 1.0)]
+        ron = [[2.0]]
+    else:
+        r_cut = [[2.5, 2.0], [2.0, 2.2]]
+        params = [orc.lj_params(1.0, 1.0), orc.lj_params(0.8, 1.5), orc.lj_params(0.8, 1.5), orc.lj_params(0.88, 0.5)]
+        ron = [[2.0, 1.5], [1.5, 2.4]]  # last: r_on > r_cut -> plain shift (hoomd/md/PotentialPair.h:693-697)
+    rcutsq = np.square(r_cut)
+    ronsq = np.square(ron)
+    pos_t = torch.from_numpy(pos).cuda()
+    nl, _, _ = gpu_nlist(K, A, pos_t, N, gbox, obox, r_cut, 0.4)
+    half = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=False)
+    F_ref, V_ref = orc.pair_forces(orc.EV_LJ, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], params, rcutsq,
+                                   ronsq, shift_mode=shift_mode, third_law=True, compute_virial=True)
+    for tpp in (1, 8, 64):
+        F, V = K.pair_forces("lj", pos_t, N, gbox, nl["n_neigh"], nl["nlist"], nl["head"], params, rcutsq, ronsq,
+                             shift_mode=shift_mode, compute_virial=True, tpp=tpp)
+        F, V = F.cpu().numpy(), V.cpu().numpy()
+        assert _rel_err(F[:, :3], F_ref[:, :3]) < F_RTOL * 1e-4
+        assert _rel_err(F[:, 3], F_ref[:, 3]) < F_RTOL * 1e-4
+        assert _rel_err(V, V_ref) < F_RTOL * 1e-4
+    # without the virial flag the force output is unchanged
+    F2, _ = K.pair_forces("lj", pos_t, N, gbox, nl["n_neigh"], nl["nlist"], nl["head"], params, rcutsq, ronsq,
+                          shift_mode=shift_mode, compute_virial=False)
+    assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
+
+
+def test_lj_reference_mathematica_values(K, A):
+    with open(os.path.join(G, "lj_forces_and_energies.json")) as f:
+        fe = json.load(f)
+    gbox, obox = boxes(A, 20.0)
+    for params, forces, energies in zip(fe["LJ"]["params"], fe["LJ"]["forces"], fe["LJ"]["energies"]):
+        for d, f_ref, e_ref in zip(fe["distances"], forces, energies):
+            pos = torch.from_numpy(orc.pack_pos([[0, 0, 0.1], [0, 0, d + 0.1]], [0, 0])).cuda()
+            nl, _, _ = gpu_nlist(K, A, pos, 2, gbox, obox, [[2.5]], 0.4)
+            F, _ = K.pair_forces("lj", pos, 2, gbox, nl["n_neigh"], nl["nlist"], nl["head"],
+                                 [orc.lj_params(params["sigma"], params["epsilon"])], [[6.25]])
+            F = F.cpu().numpy()
+            assert np.isclose(F[:, 3].sum(), e_ref, rtol=5e-6, atol=1e-6 if e_ref == 0 else 0)
+            assert np.allclose(F[0, :3], [0, 0, f_ref], rtol=1e-5, atol=1e-8)
+
+
+def test_example_plugin_evaluator(K, A):
+    """example_plugins/pair_plugin/pytest/test_example_pair.py:15-81: harmonic pair, 3 distances x
+    3 k x 3 sigma x {none, shift}, checked against the closed form to 6 decimals -- plus the oracle."""
+    gbox, obox = boxes(A, 20.0)
+    for d in (0.5, 0.75, 1.0):
+        for k in (1.0, 20.0, 100.0):
+            for sigma in (0.5, 1.0, 1.5):
+                for mode in (0, 1):
+                    r_cut = 2.0
+                    pos = torch.from_numpy(orc.pack_pos([[0, 0, 0.1], [0, 0, d + 0.1]], [0, 0])).cuda()
+                    nl, _, _ = gpu_nlist(K, A, pos, 2, gbox, obox, [[r_cut]], 0.4)
+                    F, _ = K.pair_forces("example", pos, 2, gbox, nl["n_neigh"], nl["nlist"], nl["head"], [(k, sigma)],
+                                         [[r_cut**2]], shift_mode=mode)
+                    F = F.cpu().numpy()
+                    e = 0.5 * k * (sigma - d) ** 2 - (0.5 * k * (sigma - r_cut) ** 2 if mode else 0.0)
+                    np.testing.assert_array_almost_equal(F[0, :3], [0, 0, -k * (sigma - d)], decimal=6)
+                    np.testing.assert_almost_equal(F[:, 3].sum(), e, decimal=6)
+    xyz, typ, L = liquid(8, seed=12)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    pos_t = torch.from_numpy(pos).cuda()
+    nl, _, _ = gpu_nlist(K, A, pos_t, N, gbox, obox, [[1.6]], 0.3)
+    ref = orc.nlist_binned(pos, N, obox, [[1.6]], 0.3, storage_full=True)
+    F_ref, V_ref = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(30.0, 1.2)], [[2.56]])
+    F, V = K.pair_forces("example", pos_t, N, gbox, nl["n_neigh"], nl["nlist"], nl["head"], [(30.0, 1.2)], [[2.56]])
+    assert _rel_err(F.cpu().numpy(), F_ref) < F_RTOL * 1e-4 and _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
+
+
+def test_pair_force_rejects_bad_arguments(K, A):
+    import ctypes as C
+    a = A.PairArgs()
+    a.threads_per_particle = 3
+    assert A.lib.hmd_compute_pair_forces_lj(C.byref(a), None, None) < 0
+    with pytest.raises(A.KernelError):
+        A.check(A.lib.hmd_compute_pair_forces_lj(C.byref(a), None, None), "x")
+
+
+# ------------------------------------------------------------------ integrator
+def test_half_steps_bit_exact_vs_oracle(K, A):
+    xyz, typ, L = liquid(10, seed=14)
+    N = len(xyz)
+    rng = np.random.default_rng(3)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    pos[:8, 0] = L / 2 - 1e-4  # these will cross the +x face
+    pos[8:16, 2] = -L / 2 + 1e-4
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    vel[:8, 0] = 1.0
+    vel[8:16, 2] = -1.0
+    accel = rng.normal(0, 5.0, (N, 3))
+    image = rng.integers(-2, 3, (N, 3)).astype(np.int32)
+    nf = np.concatenate([rng.normal(0, 7.0, (N, 3)), rng.normal(-3, 1, (N, 1))], 1)
+    group = rng.permutation(N)[: N // 2].astype(np.uint32)
+    for grp, rescale in ((None, 1.0), (group, 0.97)):
+        p, v, a_, im = pos.copy(), vel.copy(), accel.copy(), image.copy()
+        orc.step_one(p, v, a_, im, obox, 0.005, rescale, grp)
+        tp, tv, ta, ti = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image))
+        tg = torch.from_numpy(grp.view(np.int32)).cuda() if grp is not None else None
+        K.step_one(tp, tv, ta, ti, gbox, 0.005, rescale, tg)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v)
+        assert np.array_equal(ti.cpu().numpy(), im)
+        assert not np.array_equal(im, image)  # some images changed
+        v2, a2 = v.copy(), a_.copy()
+        orc.step_two(v2, a2, nf, 0.005, rescale, grp)
+        tnf = torch.from_numpy(nf).cuda()
+        K.step_two(tv, ta, tnf, 0.005, rescale, tg)
+        assert np.array_equal(tv.cpu().numpy(), v2) and np.array_equal(ta.cpu().numpy(), a2)
+    acc = K.compute_accelerations(torch.from_numpy(vel).cuda(), torch.from_numpy(nf).cuda())
+    assert np.array_equal(acc.cpu().numpy(), orc.compute_accel(vel, nf))
+
+
+def test_sum_net_force_and_thermo(K, A):
+    rng = np.random.default_rng(4)
+    N = 5000
+    fs = [rng.normal(0, 1, (N, 4)) for _ in range(3)]
+    vs = [rng.normal(0, 1, (6, N)) for _ in range(3)]
+    nf_ref, nv_ref = orc.sum_net_force(fs, vs)
+    nf, nv = K.sum_net_force([torch.from_numpy(f).cuda() for f in fs], [torch.from_numpy(v).cuda() for v in vs])
+    assert np.array_equal(nf.cpu().numpy(), nf_ref) and np.array_equal(nv.cpu().numpy(), nv_ref)
+    # accumulate on top (clear = False)
+    nf2, _ = K.sum_net_force([torch.from_numpy(fs[0]).cuda()], None, net_force=nf.clone(), clear=False)
+    assert np.array_equal(nf2.cpu().numpy(), nf_ref + fs[0])
+    vel = np.concatenate([rng.normal(0, 1.2, (N, 3)), rng.uniform(0.5, 2, (N, 1))], 1)
+    ke, pe = orc.thermo(vel, nf_ref)
+    out = K.thermo(torch.from_numpy(vel).cuda(), nf, nv)
+    assert np.isclose(out[0], ke, rtol=1e-12) and np.isclose(out[1], pe, rtol=1e-11, atol=1e-9)
+    assert np.isclose(out[2], (nv_ref[0] + nv_ref[3] + nv_ref[5]).sum(), rtol=1e-10, atol=1e-9)
+    assert np.allclose(out[3:6], (vel[:, :3] * vel[:, 3:4]).sum(0), rtol=1e-10, atol=1e-9)
+    out2 = K.thermo(torch.from_numpy(vel).cuda(), nf, nv)
+    assert np.array_equal(out, out2)  # fixed reduction tree: reproducible
+
+
+# ------------------------------------------------------------------ reorder + halo helpers
+def test_cell_order_permutation_and_gather(K, A):
+    xyz, typ, L = liquid(12, seed=30)
+    N = len(xyz)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(N)
+    xyz = xyz[perm]
+    gbox, obox = boxes(A, L)
+    dim = orc.cell_dimensions(obox, 2.9)
+    pos = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
+    cl = K.cell_list_auto(pos, N, 0, gbox, dim)
+    order, offs = K.cell_order(cl, N)
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(N))
+    cs = cl["cell_size"].cpu().numpy()
+    of = offs.cpu().numpy()
+    assert np.array_equal(of, np.concatenate([[0], np.cumsum(cs)]))
+    xyzf = cl["xyzf"].cpu().numpy()
+    for c in range(0, len(cs), 5):
+        assert np.array_equal(o[of[c]:of[c + 1]], orc.unpack_int_w(xyzf[c, :cs[c], 3]))
+    newpos = K.gather_rows(pos, order)
+    assert np.array_equal(newpos.cpu().numpy(), pos.cpu().numpy()[o])
+    img = torch.from_numpy(rng.integers(-3, 3, (N, 3)).astype(np.int32)).cuda()
+    assert np.array_equal(K.gather_rows(img, order).cpu().numpy(), img.cpu().numpy()[o])
+    acc = torch.from_numpy(rng.normal(0, 1, (N, 3))).cuda()
+    assert np.array_equal(K.gather_rows(acc, order).cpu().numpy(), acc.cpu().numpy()[o])
+    tag = K.gather_rows(torch.arange(N, dtype=torch.int32).cuda(), order)
+    rtag = K.build_rtag(tag)
+    assert np.array_equal(tag.cpu().numpy()[rtag.cpu().numpy()], np.arange(N))
+
+
+def test_ghost_plan_and_pack(K, A):
+    rng = np.random.default_rng(12)
+    L = (10.0, 12.0, 14.0)
+    gbox, obox = boxes(A, L, periodic=(0, 0, 1))
+    N = 4000
+    xyz = (rng.random((N, 3)) - 0.5) * np.array(L)
+    typ = rng.integers(0, 2, N)
+    pos = orc.pack_pos(xyz, typ)
+    rg = np.array([2.9, 2.4])
+    plan = K.ghost_plan(torch.from_numpy(pos).cuda(), N, gbox, rg, mask=0b001111).cpu().numpy()
+    want = np.zeros(N, dtype=np.int32)
+    for i in range(N):
+        f = orc.make_fraction(obox, xyz[i])
+        g = rg[typ[i]] / np.array(L)
+        for d in range(3):
+            if f[d] >= 1.0 - g[d]:
+                want[i] |= 1 << (2 * d)
+            if f[d] < g[d]:
+                want[i] |= 1 << (2 * d + 1)
+    assert np.array_equal(plan, want & 0b001111)
+    send = torch.from_numpy(rng.integers(0, N, 900).astype(np.int32)).cuda()
+    sid = rng.integers(0, 27, 900).astype(np.uint8)
+    table = np.array([[(i % 3 - 1) * L[0], ((i // 3) % 3 - 1) * L[1], (i // 9 - 1) * L[2]] for i in range(27)])
+    out = K.pack_ghost_positions(torch.from_numpy(pos).cuda(), send, torch.from_numpy(sid).cuda(), torch.from_numpy(table).cuda())
+    s = send.cpu().numpy()
+    exp = pos[s].copy()
+    exp[:, :3] += table[sid]
+    assert np.array_equal(out.cpu().numpy(), exp)
