@@ -10,6 +10,9 @@
 // (match-any by iterated readfirstlane), the leader reserves `count` slots with ONE atomicAdd and
 // every lane takes base + its rank.  That keeps the HBM-side atomic traffic at one request per
 // (wave, distinct cell) instead of one per particle.
+// Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
+// following sum (the CPU path rounds every product and sum separately).
+#pragma clang fp contract(off)
 #include "common.cuh"
 
 namespace

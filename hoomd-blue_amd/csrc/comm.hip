@@ -2,6 +2,9 @@
 //
 // Contracts: hoomd/CommunicatorGPU.cu:306-372 (ghost plan), :778-875 (pack / pack with periodic
 // shift).  The exchange itself (RCCL all-to-all over xGMI) is driven from the host layer.
+// Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
+// following sum (the CPU path rounds every product and sum separately).
+#pragma clang fp contract(off)
 #include "common.cuh"
 
 namespace

@@ -62,10 +62,13 @@ __device__ __forceinline__ void hmd_st4(hmd_scalar4* p, double x, double y, doub
     }
 
 // The functions below implement bit-exact comparisons against the CPU path, so no product may be
-// fused into a following sum: they use the round-to-nearest intrinsics, which are never contracted.
-#define HMD_MUL(a, b) __dmul_rn((a), (b))
-#define HMD_ADD(a, b) __dadd_rn((a), (b))
-#define HMD_SUB(a, b) __dsub_rn((a), (b))
+// fused into a following sum.  HIP's __dmul_rn/__dadd_rn are plain operators and can be contracted,
+// so the guarantee comes from the translation unit: every unit that uses these helpers for a
+// bit-exact result sets `#pragma clang fp contract(off)` before including this header and is
+// compiled with -ffp-contract=off (csrc/Makefile).  The macros only mark the places that rely on it.
+#define HMD_MUL(a, b) ((a) * (b))
+#define HMD_ADD(a, b) ((a) + (b))
+#define HMD_SUB(a, b) ((a) - (b))
 
 // BoxDim::makeFraction (hoomd/BoxDim.h:260-268), products and sums rounded separately.
 __device__ __forceinline__ double3 hmd_make_fraction(const hmd_box_t& b, double x, double y, double z, const hmd_scalar3& gw)

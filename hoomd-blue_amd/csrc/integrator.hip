@@ -5,6 +5,9 @@
 // half step reproduces the CPU path bit for bit; hoomd/Integrator.cu:67-230 (net force);
 // hoomd/Integrator.cc:106-127 (accelerations); hoomd/md/ComputeThermoGPU.cu (reductions).
 // All of these stream each array once: 16-byte vector accesses, one lane per particle.
+// Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
+// following sum (the CPU path rounds every product and sum separately).
+#pragma clang fp contract(off)
 #include "common.cuh"
 
 namespace

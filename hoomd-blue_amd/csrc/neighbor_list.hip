@@ -15,6 +15,9 @@
 // with a ballot + lane-rank prefix so that hits are appended contiguously to the padded row
 // nlist[head_i ...].  Candidate traffic from memory is therefore one read per (cell, candidate)
 // instead of one per (particle, candidate); the row writes are dense 4-byte runs.
+// Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
+// following sum (the CPU path rounds every product and sum separately).
+#pragma clang fp contract(off)
 #include "common.cuh"
 
 namespace

@@ -3,6 +3,9 @@
 // (hoomd/SFCPackTunerGPU.cu:26-160): instead of binning on a separate 256^3 grid and running a
 // global key sort, the permutation is read off the cell list that the neighbor build already
 // made -- an exclusive scan of the cell occupancies gives each cell's first new index.
+// Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
+// following sum (the CPU path rounds every product and sum separately).
+#pragma clang fp contract(off)
 #include "common.cuh"
 
 namespace
