@@ -1,0 +1,1384 @@
+// hoomd_host.h -- C++ host layer above the C ABI (include/hoomd_amd.h).
+//
+// The classes keep the reference's names, virtual interfaces and host-side bookkeeping for the
+// short-range MD path (ParticleData, CellList, NeighborList, ForceCompute, PotentialPair,
+// IntegrationMethodTwoStep, Integrator, System, Communicator); the work itself is done by the gfx950
+// kernel drivers.  Reference files are cited next to each class (paths relative to HOOMD-blue 4.1.0).
+// Everything runs on one HIP stream (the default stream, as the reference does); device memory is
+// owned by DeviceArray members; the only host<->device traffic per step is the 4-byte rebuild flag
+// and, on rebuild steps, the small overflow/condition words.
+#ifndef HOOMD_HOST_H
+#define HOOMD_HOST_H
+
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hoomd_amd.h"
+
+namespace hoomd_amd
+    {
+typedef double Scalar;
+typedef hmd_scalar4 Scalar4;
+typedef hmd_scalar3 Scalar3;
+typedef hmd_int3 int3;
+
+void hipCheck(hipError_t e, const char* what);
+void abiCheck(int code, const char* what);
+
+// ---------------------------------------------------------------------------------------------
+// Device memory (role of GlobalArray / GPUArray, hoomd/GlobalArray.h, hoomd/GPUArray.h)
+// ---------------------------------------------------------------------------------------------
+template<class T> class DeviceArray
+    {
+    public:
+    DeviceArray() = default;
+    explicit DeviceArray(size_t n)
+        {
+        resize(n, false);
+        }
+    ~DeviceArray()
+        {
+        release();
+        }
+    DeviceArray(const DeviceArray&) = delete;
+    DeviceArray& operator=(const DeviceArray&) = delete;
+
+    //! grow or shrink; contents are kept up to min(old, new) when keep is set; new memory is zeroed
+    void resize(size_t n, bool keep = true)
+        {
+        if (n == m_n)
+            return;
+        T* p = nullptr;
+        if (n)
+            {
+            hipCheck(hipMalloc((void**)&p, n * sizeof(T)), "hipMalloc");
+            hipCheck(hipMemsetAsync(p, 0, n * sizeof(T), 0), "hipMemsetAsync");
+            if (keep && m_p && m_n)
+                hipCheck(hipMemcpyAsync(p, m_p, (n < m_n ? n : m_n) * sizeof(T), hipMemcpyDeviceToDevice, 0), "hipMemcpyAsync");
+            }
+        if (m_p)
+            {
+            hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+            hipCheck(hipFree(m_p), "hipFree");
+            }
+        m_p = p;
+        m_n = n;
+        }
+    void release()
+        {
+        if (m_p)
+            (void)hipFree(m_p);
+        m_p = nullptr;
+        m_n = 0;
+        }
+    void swap(DeviceArray& o)
+        {
+        std::swap(m_p, o.m_p);
+        std::swap(m_n, o.m_n);
+        }
+    void zero()
+        {
+        if (m_n)
+            hipCheck(hipMemsetAsync(m_p, 0, m_n * sizeof(T), 0), "hipMemsetAsync");
+        }
+    T* get() const
+        {
+        return m_p;
+        }
+    size_t size() const
+        {
+        return m_n;
+        }
+    void upload(const T* h, size_t n, size_t offset = 0)
+        {
+        if (n)
+            hipCheck(hipMemcpy(m_p + offset, h, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        }
+    void download(T* h, size_t n, size_t offset = 0) const
+        {
+        if (n)
+            hipCheck(hipMemcpy(h, m_p + offset, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        }
+    std::vector<T> toHost(size_t n = (size_t)-1) const
+        {
+        if (n == (size_t)-1)
+            n = m_n;
+        std::vector<T> v(n);
+        download(v.data(), n);
+        return v;
+        }
+
+    private:
+    T* m_p = nullptr;
+    size_t m_n = 0;
+    };
+
+//! small pinned host word block for flag readbacks
+class PinnedWords
+    {
+    public:
+    explicit PinnedWords(size_t n);
+    ~PinnedWords();
+    unsigned int* get()
+        {
+        return m_p;
+        }
+
+    private:
+    unsigned int* m_p = nullptr;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// signals (role of Nano::Signal, used for particle-sort / box-change / r_cut-change notifications)
+// ---------------------------------------------------------------------------------------------
+class Signal
+    {
+    public:
+    int connect(std::function<void()> f)
+        {
+        m_slots.emplace_back(m_next, std::move(f));
+        return m_next++;
+        }
+    void disconnect(int id)
+        {
+        for (size_t i = 0; i < m_slots.size(); i++)
+            if (m_slots[i].first == id)
+                {
+                m_slots.erase(m_slots.begin() + i);
+                return;
+                }
+        }
+    void emit() const
+        {
+        for (auto& s : m_slots)
+            s.second();
+        }
+
+    private:
+    std::vector<std::pair<int, std::function<void()>>> m_slots;
+    int m_next = 0;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Box (hoomd/BoxDim.h) -- thin value wrapper around hmd_box_t
+// ---------------------------------------------------------------------------------------------
+struct BoxDim
+    {
+    hmd_box_t b;
+    BoxDim()
+        {
+        hmd_box_init(&b, 1, 1, 1, 0, 0, 0);
+        }
+    BoxDim(Scalar Lx, Scalar Ly, Scalar Lz, Scalar xy = 0, Scalar xz = 0, Scalar yz = 0)
+        {
+        hmd_box_init(&b, Lx, Ly, Lz, xy, xz, yz);
+        }
+    void setLoHi(const Scalar lo[3], const Scalar hi[3])
+        {
+        hmd_box_set_lo_hi(&b, lo, hi);
+        }
+    void setPeriodic(bool x, bool y, bool z)
+        {
+        b.periodic[0] = x;
+        b.periodic[1] = y;
+        b.periodic[2] = z;
+        }
+    std::array<Scalar, 3> getNearestPlaneDistance() const
+        {
+        return {b.nearest_plane[0], b.nearest_plane[1], b.nearest_plane[2]};
+        }
+    Scalar getVolume(bool twod = false) const
+        {
+        return twod ? b.L[0] * b.L[1] : b.L[0] * b.L[1] * b.L[2];
+        }
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Snapshot exchanged with Python (hoomd/SnapshotSystemData.h, hoomd/ParticleData.h:168-262)
+// ---------------------------------------------------------------------------------------------
+struct SnapshotParticleData
+    {
+    std::vector<std::array<Scalar, 3>> pos, vel, accel;
+    std::vector<unsigned int> type, body;
+    std::vector<unsigned int> tag; //!< global tags of the rows; empty on input means 0..N-1
+    std::vector<Scalar> mass, charge, diameter;
+    std::vector<std::array<int, 3>> image;
+    std::vector<std::string> type_mapping;
+    void resize(unsigned int n);
+    unsigned int size = 0;
+    };
+
+enum pdata_flag
+    {
+    pressure_tensor = 0,
+    rotational_kinetic_energy,
+    external_field_virial
+    };
+
+class Communicator;
+
+// ---------------------------------------------------------------------------------------------
+// ParticleData (hoomd/ParticleData.h:1308-1357 array set; only what the path touches)
+// ---------------------------------------------------------------------------------------------
+class ParticleData
+    {
+    public:
+    //! n_global = 0 means the snapshot holds every particle (single rank)
+    ParticleData(const SnapshotParticleData& snap, const BoxDim& global_box, unsigned int n_global = 0);
+
+    unsigned int getN() const
+        {
+        return m_N;
+        }
+    unsigned int getNGhosts() const
+        {
+        return m_nghost;
+        }
+    unsigned int getNGlobal() const
+        {
+        return m_nglobal;
+        }
+    void setNGlobal(unsigned int n)
+        {
+        m_nglobal = n;
+        }
+    unsigned int getMaxN() const
+        {
+        return m_maxn;
+        }
+    unsigned int getNTypes() const
+        {
+        return (unsigned int)m_type_mapping.size();
+        }
+    const std::vector<std::string>& getTypeMapping() const
+        {
+        return m_type_mapping;
+        }
+    unsigned int getTypeByName(const std::string& name) const;
+
+    const BoxDim& getBox() const
+        {
+        return m_box;
+        }
+    const BoxDim& getGlobalBox() const
+        {
+        return m_global_box;
+        }
+    //! local box differs from the global one under domain decomposition
+    void setBoxes(const BoxDim& global_box, const BoxDim& local_box);
+
+    //! owned-particle count changes (migration); arrays grow geometrically, contents kept
+    void resizeOwned(unsigned int n);
+    //! ghosts live at [N, N+nghost)
+    void setNGhosts(unsigned int n);
+    void reallocate(unsigned int max_n);
+
+    // device arrays
+    Scalar4* pos() const
+        {
+        return m_pos.get();
+        }
+    Scalar4* vel() const
+        {
+        return m_vel.get();
+        }
+    Scalar3* accel() const
+        {
+        return m_accel.get();
+        }
+    int3* image() const
+        {
+        return m_image.get();
+        }
+    unsigned int* tag() const
+        {
+        return m_tag.get();
+        }
+    unsigned int* rtag() const
+        {
+        return m_rtag.get();
+        }
+    unsigned int* body() const
+        {
+        return m_body.get();
+        }
+    Scalar* charge() const
+        {
+        return m_charge.get();
+        }
+    Scalar* diameter() const
+        {
+        return m_diameter.get();
+        }
+    Scalar4* netForce() const
+        {
+        return m_net_force.get();
+        }
+    Scalar* netVirial() const
+        {
+        return m_net_virial.get();
+        }
+    size_t netVirialPitch() const
+        {
+        return m_maxn;
+        }
+    //! when a single force compute feeds the integrator its force array IS the net force
+    void aliasNetForce(Scalar4* p)
+        {
+        m_net_force_alias = p;
+        }
+    Scalar4* netForceForIntegration() const
+        {
+        return m_net_force_alias ? m_net_force_alias : m_net_force.get();
+        }
+
+    bool isAccelSet() const
+        {
+        return m_accel_set;
+        }
+    void notifyAccelSet()
+        {
+        m_accel_set = true;
+        }
+
+    bool getFlag(pdata_flag f) const
+        {
+        return (m_flags >> f) & 1u;
+        }
+    unsigned int getFlags() const
+        {
+        return m_flags;
+        }
+    void setFlags(unsigned int f)
+        {
+        m_flags = f;
+        }
+
+    //! apply a permutation: new[k] = old[order[k]] to every per-particle array, rebuild rtag, emit sort signal
+    void applyOrder(const unsigned int* d_order);
+    void notifyParticleSort()
+        {
+        m_sort_count++;
+        m_sort_signal.emit();
+        }
+    //! number of reorderings so far (lets the Python-level communicator notice a sort)
+    uint64_t getSortCount() const
+        {
+        return m_sort_count;
+        }
+    Signal& getParticleSortSignal()
+        {
+        return m_sort_signal;
+        }
+    Signal& getBoxChangeSignal()
+        {
+        return m_box_signal;
+        }
+    Signal& getMaxParticleNumberChangeSignal()
+        {
+        return m_maxn_signal;
+        }
+    Signal& getGlobalParticleNumberChangeSignal()
+        {
+        return m_nglobal_signal;
+        }
+
+    //! owned particles in tag order (local tags only under domain decomposition)
+    void takeSnapshot(SnapshotParticleData& snap) const;
+    void initializeFromSnapshot(const SnapshotParticleData& snap);
+    //! overwrite positions/velocities/... of owned particles given full-size tag-ordered arrays
+    void setExternalEnergy(Scalar e)
+        {
+        m_external_energy = e;
+        }
+    Scalar getExternalEnergy() const
+        {
+        return m_external_energy;
+        }
+    void setExternalVirial(unsigned int i, Scalar v)
+        {
+        m_external_virial[i] = v;
+        }
+    Scalar getExternalVirial(unsigned int i) const
+        {
+        return m_external_virial[i];
+        }
+
+    private:
+    unsigned int m_N = 0, m_nghost = 0, m_nglobal = 0, m_maxn = 0;
+    BoxDim m_box, m_global_box;
+    std::vector<std::string> m_type_mapping;
+    DeviceArray<Scalar4> m_pos, m_vel, m_net_force, m_alt4;
+    DeviceArray<Scalar3> m_accel, m_alt3;
+    DeviceArray<int3> m_image, m_alti3;
+    DeviceArray<unsigned int> m_tag, m_rtag, m_body, m_altu;
+    DeviceArray<Scalar> m_charge, m_diameter, m_net_virial, m_alt1;
+    Scalar4* m_net_force_alias = nullptr;
+    bool m_accel_set = false;
+    unsigned int m_flags = 0;
+    Scalar m_external_energy = 0;
+    Scalar m_external_virial[6] = {0, 0, 0, 0, 0, 0};
+    Signal m_sort_signal, m_box_signal, m_maxn_signal, m_nglobal_signal;
+    uint64_t m_sort_count = 0;
+    };
+
+class SystemDefinition
+    {
+    public:
+    SystemDefinition(const SnapshotParticleData& snap, const BoxDim& box, unsigned int ndim, unsigned int seed, unsigned int n_global = 0)
+        : m_pdata(std::make_shared<ParticleData>(snap, box, n_global)), m_ndim(ndim), m_seed(seed)
+        {
+        }
+    std::shared_ptr<ParticleData> getParticleData() const
+        {
+        return m_pdata;
+        }
+    unsigned int getNDimensions() const
+        {
+        return m_ndim;
+        }
+    unsigned int getSeed() const
+        {
+        return m_seed;
+        }
+    bool isDomainDecomposed() const
+        {
+        return (bool)m_comm;
+        }
+    std::shared_ptr<Communicator> getCommunicator() const
+        {
+        return m_comm;
+        }
+    void setCommunicator(std::shared_ptr<Communicator> c)
+        {
+        m_comm = c;
+        }
+
+    private:
+    std::shared_ptr<ParticleData> m_pdata;
+    unsigned int m_ndim;
+    unsigned int m_seed;
+    std::shared_ptr<Communicator> m_comm;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Communicator interface (hoomd/Communicator.h:166-232).  The exchange is implemented in Python on
+// top of torch.distributed (RCCL); the host classes only see this interface.
+// ---------------------------------------------------------------------------------------------
+class Communicator
+    {
+    public:
+    virtual ~Communicator() { }
+    //! migrate / exchange ghosts or update ghost positions (hoomd/Communicator.cc:1510-1569)
+    virtual void communicate(uint64_t timestep) = 0;
+    virtual void forceMigrate() = 0;
+    //! largest ghost layer width requested by the subscribers
+    virtual Scalar getGhostLayerMaxWidth() const = 0;
+    //! global logical OR of a local flag (the rebuild vote, hoomd/md/NeighborListGPU.cc:84-98)
+    virtual bool anyRank(bool local) = 0;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Compute (hoomd/Compute.cc:42-76)
+// ---------------------------------------------------------------------------------------------
+class Compute
+    {
+    public:
+    explicit Compute(std::shared_ptr<SystemDefinition> sysdef) : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()) { }
+    virtual ~Compute() { }
+    virtual void compute(uint64_t timestep) { }
+    void forceCompute(uint64_t timestep)
+        {
+        m_force_compute = true;
+        compute(timestep);
+        }
+
+    protected:
+    bool shouldCompute(uint64_t timestep);
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<ParticleData> m_pdata;
+    bool m_first_compute = true, m_force_compute = false;
+    uint64_t m_last_computed = 0;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// ParticleGroup (hoomd/ParticleGroup.h): all particles, or an explicit tag list
+// ---------------------------------------------------------------------------------------------
+class ParticleGroup
+    {
+    public:
+    //! group of all particles
+    explicit ParticleGroup(std::shared_ptr<SystemDefinition> sysdef);
+    //! group of the given tags
+    ParticleGroup(std::shared_ptr<SystemDefinition> sysdef, const std::vector<unsigned int>& tags);
+    ~ParticleGroup();
+    unsigned int getNumMembers();
+    unsigned int getNumMembersGlobal() const
+        {
+        return m_is_all ? m_pdata->getNGlobal() : (unsigned int)m_tags.size();
+        }
+    //! device index list, nullptr for the identity group
+    const unsigned int* getIndexArray();
+    bool isAll() const
+        {
+        return m_is_all;
+        }
+    void setTranslationalDOF(Scalar d)
+        {
+        m_dof = d;
+        }
+    Scalar getTranslationalDOF() const
+        {
+        return m_dof;
+        }
+
+    private:
+    void rebuild();
+    std::shared_ptr<ParticleData> m_pdata;
+    bool m_is_all;
+    std::vector<unsigned int> m_tags;
+    DeviceArray<unsigned int> m_idx;
+    unsigned int m_n_local = 0;
+    bool m_dirty = true;
+    int m_slot = -1;
+    Scalar m_dof = 0;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// CellList / CellListGPU (hoomd/CellList.{h,cc}, hoomd/CellListGPU.{h,cc})
+// ---------------------------------------------------------------------------------------------
+class CellListGPU : public Compute
+    {
+    public:
+    explicit CellListGPU(std::shared_ptr<SystemDefinition> sysdef);
+    ~CellListGPU();
+
+    void setNominalWidth(Scalar w)
+        {
+        m_nominal_width = w;
+        m_params_changed = true;
+        }
+    void setRadius(unsigned int r)
+        {
+        m_radius = r;
+        m_params_changed = true;
+        }
+    void setComputeTypeBody(bool b)
+        {
+        m_compute_type_body = b;
+        m_params_changed = true;
+        }
+    void setComputeIdx(bool b)
+        {
+        m_compute_idx = b;
+        m_params_changed = true;
+        }
+    void setFlagIndex()
+        {
+        m_flag_charge = m_flag_type = false;
+        m_params_changed = true;
+        }
+    void setFlagCharge()
+        {
+        m_flag_charge = true;
+        m_flag_type = false;
+        m_params_changed = true;
+        }
+    void setFlagType()
+        {
+        m_flag_type = true;
+        m_flag_charge = false;
+        m_params_changed = true;
+        }
+    void setSortCellList(bool s)
+        {
+        m_sort = s;
+        m_params_changed = true;
+        }
+    void setMultiple(unsigned int m)
+        {
+        m_multiple = m ? m : 1;
+        m_params_changed = true;
+        }
+    std::array<unsigned int, 3> getDim() const
+        {
+        return m_dim;
+        }
+    Scalar3 getGhostWidth() const
+        {
+        return m_ghost_width;
+        }
+    unsigned int getNmax() const
+        {
+        return m_Nmax;
+        }
+    hmd_index3d_t getCellIndexer() const
+        {
+        return hmd_index3d_t {m_dim[0], m_dim[1], m_dim[2]};
+        }
+    hmd_index2d_t getCellListIndexer() const
+        {
+        return hmd_index2d_t {m_Nmax, m_dim[0] * m_dim[1] * m_dim[2]};
+        }
+    hmd_index2d_t getCellAdjIndexer() const
+        {
+        return hmd_index2d_t {m_n_adj, m_dim[0] * m_dim[1] * m_dim[2]};
+        }
+    const DeviceArray<unsigned int>& getCellSizeArray() const
+        {
+        return m_cell_size;
+        }
+    const DeviceArray<Scalar4>& getXYZFArray() const
+        {
+        return m_xyzf;
+        }
+    const DeviceArray<hmd_uint2>& getTypeBodyArray() const
+        {
+        return m_type_body;
+        }
+    const DeviceArray<unsigned int>& getIndexArray() const
+        {
+        return m_idx;
+        }
+    const DeviceArray<unsigned int>& getCellAdjArray() const
+        {
+        return m_cell_adj;
+        }
+    void compute(uint64_t timestep) override;
+    std::array<unsigned int, 3> computeDimensions();
+
+    private:
+    void initializeAll();
+    void initializeWidth();
+    void initializeMemory();
+    void initializeCellAdj();
+    void computeCellList();
+    bool checkConditions();
+
+    Scalar m_nominal_width = 0;
+    unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0;
+    std::array<unsigned int, 3> m_dim {{0, 0, 0}};
+    Scalar3 m_ghost_width {0, 0, 0};
+    bool m_params_changed = true, m_particles_sorted = false, m_box_changed = false;
+    bool m_compute_type_body = false, m_compute_idx = false, m_flag_charge = false, m_flag_type = false, m_sort = false;
+    DeviceArray<unsigned int> m_cell_size, m_cell_adj, m_idx;
+    DeviceArray<Scalar4> m_xyzf;
+    DeviceArray<hmd_uint2> m_type_body;
+    DeviceArray<hmd_uint3> m_conditions;
+    PinnedWords m_h_cond;
+    int m_sort_slot, m_box_slot;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// NeighborList (hoomd/md/NeighborList.{h,cc}) + NeighborListGPU + NeighborListGPUBinned
+// ---------------------------------------------------------------------------------------------
+class NeighborListGPUBinned : public Compute
+    {
+    public:
+    enum storageMode
+        {
+        half,
+        full
+        };
+    NeighborListGPUBinned(std::shared_ptr<SystemDefinition> sysdef, Scalar r_buff);
+    ~NeighborListGPUBinned();
+
+    // ---- r_cut matrices (hoomd/md/NeighborList.h:230-262) ----
+    void addRCutMatrix(std::shared_ptr<std::vector<Scalar>> m);
+    void removeRCutMatrix(std::shared_ptr<std::vector<Scalar>> m);
+    void notifyRCutMatrixChange()
+        {
+        m_rcut_changed = true;
+        forceUpdate();
+        }
+    void setRBuff(Scalar r_buff);
+    Scalar getRBuff() const
+        {
+        return m_r_buff;
+        }
+    void setRebuildCheckDelay(uint64_t d)
+        {
+        m_rebuild_check_delay = d;
+        forceUpdate();
+        }
+    uint64_t getRebuildCheckDelay() const
+        {
+        return m_rebuild_check_delay;
+        }
+    void setDistCheck(bool b)
+        {
+        m_dist_check = b;
+        forceUpdate();
+        }
+    bool getDistCheck() const
+        {
+        return m_dist_check;
+        }
+    void setStorageMode(storageMode m);
+    storageMode getStorageMode() const
+        {
+        return m_storage_mode;
+        }
+    void setFilterBody(bool f)
+        {
+        m_filter_body = f;
+        forceUpdate();
+        }
+    void setDeterministic(bool d);
+    bool getDeterministic() const
+        {
+        return m_deterministic;
+        }
+    Scalar getMaxRCut()
+        {
+        if (m_rcut_changed)
+            updateRList();
+        return m_rcut_max_max;
+        }
+    Scalar getMinRCut()
+        {
+        if (m_rcut_changed)
+            updateRList();
+        return m_rcut_min;
+        }
+    Scalar getMaxRList()
+        {
+        return getMaxRCut() + m_r_buff;
+        }
+    Scalar getMinRList()
+        {
+        return getMinRCut() + m_r_buff;
+        }
+    //! ghost layer width the communicator must provide (hoomd/md/NeighborList.h:379-397)
+    Scalar getGhostLayerWidth()
+        {
+        Scalar r = getMaxRCut();
+        return r > 0 ? r + m_r_buff : 0;
+        }
+
+    void forceUpdate()
+        {
+        m_force_update = true;
+        }
+    uint64_t getNumUpdates() const
+        {
+        return m_updates + m_forced_updates;
+        }
+    unsigned int getSmallestRebuild() const;
+    uint64_t getNumDangerousUpdates() const
+        {
+        return m_dangerous_updates;
+        }
+    void resetStats();
+
+    // ---- exclusions (hoomd/md/NeighborList.cc:569-1211), tag based ----
+    void clearExclusions();
+    void addExclusion(unsigned int tag1, unsigned int tag2);
+    unsigned int getNumExclusions() const
+        {
+        return m_n_exclusions;
+        }
+
+    void compute(uint64_t timestep) override;
+    bool needsUpdating(uint64_t timestep);
+    bool peekUpdate(uint64_t timestep)
+        {
+        return needsUpdating(timestep);
+        }
+
+    const DeviceArray<unsigned int>& getNNeighArray() const
+        {
+        return m_n_neigh;
+        }
+    const DeviceArray<unsigned int>& getNListArray() const
+        {
+        return m_nlist;
+        }
+    const DeviceArray<size_t>& getHeadList() const
+        {
+        return m_head_list;
+        }
+    std::array<unsigned int, 3> getDim() const
+        {
+        return m_cl->getDim();
+        }
+    unsigned int getNmax() const
+        {
+        return m_cl->getNmax();
+        }
+    std::shared_ptr<CellListGPU> getCellList() const
+        {
+        return m_cl;
+        }
+    //! (i, j) index pairs with i < j of the current list, local indices
+    std::vector<std::pair<unsigned int, unsigned int>> getLocalPairList();
+    //! same by tag
+    std::vector<std::pair<unsigned int, unsigned int>> getPairList();
+    std::vector<unsigned int> getNmaxPerType() const
+        {
+        return m_Nmax;
+        }
+
+    protected:
+    void updateRList();
+    void checkBoxSize();
+    bool distanceCheck(uint64_t timestep);
+    void buildNlist(uint64_t timestep);
+    void buildHeadList();
+    bool checkConditions();
+    void resetConditions();
+    void resizeNlist(size_t size);
+    void updateExListIdx();
+    void filterNlist();
+    void reallocatePerParticle();
+
+    std::shared_ptr<CellListGPU> m_cl;
+    Scalar m_r_buff;
+    bool m_filter_body = false;
+    storageMode m_storage_mode = half;
+    bool m_deterministic = false;
+    std::vector<std::shared_ptr<std::vector<Scalar>>> m_consumer_r_cut;
+    std::vector<Scalar> m_r_cut, m_rcut_max;
+    Scalar m_rcut_max_max = 0, m_rcut_min = 0;
+    bool m_rcut_changed = true, m_update_cell_size = true;
+
+    uint64_t m_updates = 0, m_forced_updates = 0, m_dangerous_updates = 0;
+    bool m_force_update = true, m_dist_check = true, m_has_been_updated_once = false;
+    uint64_t m_last_updated_tstep = 0, m_last_checked_tstep = 0, m_rebuild_check_delay = 0;
+    bool m_last_check_result = false;
+    std::vector<uint64_t> m_update_periods;
+    std::array<Scalar, 3> m_last_L {{0, 0, 0}};
+    unsigned int m_checkn = 1;
+
+    std::vector<unsigned int> m_Nmax;
+    DeviceArray<unsigned int> m_d_Nmax, m_conditions, m_n_neigh, m_nlist, m_flag;
+    DeviceArray<size_t> m_head_list, m_req_size;
+    DeviceArray<Scalar4> m_last_pos;
+    DeviceArray<Scalar> m_d_r_cut, m_d_rcut_max;
+    DeviceArray<unsigned char> m_workspace;
+    PinnedWords m_h_words;
+
+    // exclusions
+    bool m_exclusions_set = false, m_ex_dirty = false;
+    unsigned int m_n_exclusions = 0;
+    std::vector<std::vector<unsigned int>> m_ex_by_tag;
+    DeviceArray<unsigned int> m_n_ex_tag, m_ex_list_tag, m_n_ex_idx, m_ex_list_idx;
+    unsigned int m_ex_height = 0;
+
+    int m_sort_slot, m_box_slot, m_maxn_slot;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// ForceCompute (hoomd/ForceCompute.{h,cc})
+// ---------------------------------------------------------------------------------------------
+class ForceCompute : public Compute
+    {
+    public:
+    explicit ForceCompute(std::shared_ptr<SystemDefinition> sysdef);
+    ~ForceCompute();
+    void compute(uint64_t timestep) override;
+    Scalar4* getForceArray() const
+        {
+        return m_force.get();
+        }
+    Scalar* getVirialArray() const
+        {
+        return m_virial.get();
+        }
+    size_t getVirialPitch() const
+        {
+        return m_virial_pitch;
+        }
+    Scalar getExternalEnergy() const
+        {
+        return m_external_energy;
+        }
+    Scalar getExternalVirial(unsigned int i) const
+        {
+        return m_external_virial[i];
+        }
+    //! tag-ordered host copies (hoomd/ForceCompute.cc:628-643 getForces/getEnergies/getVirials)
+    std::vector<std::array<Scalar, 4>> getForcesAndEnergies();
+    std::vector<std::array<Scalar, 6>> getVirials();
+    Scalar calcEnergySum();
+
+    protected:
+    virtual void computeForces(uint64_t timestep) = 0;
+    void reallocate();
+    DeviceArray<Scalar4> m_force;
+    DeviceArray<Scalar> m_virial;
+    size_t m_virial_pitch = 0;
+    bool m_particles_sorted = false;
+    unsigned int m_computed_flags = 0;
+    Scalar m_external_energy = 0;
+    Scalar m_external_virial[6] = {0, 0, 0, 0, 0, 0};
+    int m_sort_slot, m_maxn_slot;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// PotentialPairGPU<evaluator> (hoomd/md/PotentialPair.h, hoomd/md/PotentialPairGPU.h).
+// The host-side evaluator traits carry the parameter block, the LRC integrals and the symbol of
+// the matching kernel driver (one extern "C" entry point per evaluator).
+// ---------------------------------------------------------------------------------------------
+struct EvaluatorLJHost
+    {
+    typedef hmd_lj_params_t param_type;
+    static const char* getName()
+        {
+        return "lj";
+        }
+    static int launch(const hmd_pair_args_t* a, const param_type* p, void* s)
+        {
+        return hmd_compute_pair_forces_lj(a, p, s);
+        }
+    //! hoomd/md/EvaluatorPairLJ.h:213-248
+    static Scalar energyLRC(Scalar rcutsq, const param_type& p);
+    static Scalar pressureLRC(Scalar rcutsq, const param_type& p);
+    };
+
+struct EvaluatorExampleHost
+    {
+    typedef hmd_example_params_t param_type;
+    static const char* getName()
+        {
+        return "example_pair";
+        }
+    static int launch(const hmd_pair_args_t* a, const param_type* p, void* s)
+        {
+        return hmd_compute_pair_forces_example(a, p, s);
+        }
+    static Scalar energyLRC(Scalar, const param_type&)
+        {
+        return 0;
+        }
+    static Scalar pressureLRC(Scalar, const param_type&)
+        {
+        return 0;
+        }
+    };
+
+template<class Ev> class PotentialPairGPU : public ForceCompute
+    {
+    public:
+    typedef typename Ev::param_type param_type;
+    enum energyShiftMode
+        {
+        no_shift = 0,
+        shift,
+        xplor
+        };
+    PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<NeighborListGPUBinned> nlist);
+    ~PotentialPairGPU();
+    void setParams(unsigned int typ1, unsigned int typ2, const param_type& p);
+    param_type getParams(unsigned int typ1, unsigned int typ2) const
+        {
+        return m_params[typ2 * m_ntypes + typ1];
+        }
+    void setRcut(unsigned int typ1, unsigned int typ2, Scalar rcut);
+    Scalar getRCut(unsigned int typ1, unsigned int typ2) const
+        {
+        return (*m_r_cut_nlist)[typ2 * m_ntypes + typ1];
+        }
+    void setRon(unsigned int typ1, unsigned int typ2, Scalar ron);
+    Scalar getROn(unsigned int typ1, unsigned int typ2) const;
+    void setShiftMode(energyShiftMode m)
+        {
+        m_shift_mode = m;
+        }
+    energyShiftMode getShiftMode() const
+        {
+        return m_shift_mode;
+        }
+    void setTailCorrectionEnabled(bool e)
+        {
+        m_tail = e;
+        }
+    bool getTailCorrectionEnabled() const
+        {
+        return m_tail;
+        }
+    void setThreadsPerParticle(unsigned int tpp)
+        {
+        m_tpp = tpp;
+        }
+    unsigned int getThreadsPerParticle() const
+        {
+        return m_tpp;
+        }
+    std::shared_ptr<NeighborListGPUBinned> getNeighborList() const
+        {
+        return m_nlist;
+        }
+
+    protected:
+    void computeForces(uint64_t timestep) override;
+    void computeTailCorrection();
+    std::shared_ptr<NeighborListGPUBinned> m_nlist;
+    unsigned int m_ntypes;
+    energyShiftMode m_shift_mode = no_shift;
+    bool m_tail = false, m_tables_dirty = true;
+    unsigned int m_tpp = 0;
+    std::vector<param_type> m_params;
+    std::vector<Scalar> m_rcutsq, m_ronsq;
+    std::shared_ptr<std::vector<Scalar>> m_r_cut_nlist;
+    DeviceArray<param_type> m_d_params;
+    DeviceArray<Scalar> m_d_rcutsq, m_d_ronsq;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// ComputeThermoGPU (hoomd/md/ComputeThermo.{h,cc}, hoomd/md/ComputeThermoGPU.cu)
+// ---------------------------------------------------------------------------------------------
+class ComputeThermoGPU : public Compute
+    {
+    public:
+    ComputeThermoGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ParticleGroup> group);
+    void compute(uint64_t timestep) override;
+    Scalar getTranslationalKineticEnergy() const
+        {
+        return m_vals[0];
+        }
+    Scalar getKineticEnergy() const
+        {
+        return m_vals[0];
+        }
+    Scalar getPotentialEnergy() const
+        {
+        return m_vals[1];
+        }
+    Scalar getVirialTrace() const
+        {
+        return m_vals[2];
+        }
+    std::array<Scalar, 3> getMomentum() const
+        {
+        return {m_vals[3], m_vals[4], m_vals[5]};
+        }
+    Scalar getTranslationalDOF() const
+        {
+        return m_group->getTranslationalDOF();
+        }
+    Scalar getTranslationalTemperature() const
+        {
+        return 2.0 * m_vals[0] / m_group->getTranslationalDOF();
+        }
+    Scalar getPressure() const;
+    //! hook for summing over ranks (set by the Python communicator)
+    std::function<void(double*, int)> m_allreduce_sum;
+
+    private:
+    std::shared_ptr<ParticleGroup> m_group;
+    DeviceArray<Scalar> m_out;
+    DeviceArray<unsigned char> m_scratch;
+    std::array<Scalar, 8> m_vals {{0, 0, 0, 0, 0, 0, 0, 0}};
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Thermostats (hoomd/md/Thermostat.h)
+// ---------------------------------------------------------------------------------------------
+class Thermostat
+    {
+    public:
+    Thermostat(Scalar T, std::shared_ptr<ParticleGroup> group, std::shared_ptr<ComputeThermoGPU> thermo, std::shared_ptr<SystemDefinition> sysdef)
+        : m_T(T), m_group(group), m_thermo(thermo), m_sysdef(sysdef)
+        {
+        }
+    virtual ~Thermostat() { }
+    virtual std::array<Scalar, 2> getRescalingFactorsOne(uint64_t timestep, Scalar deltaT)
+        {
+        return {1.0, 1.0};
+        }
+    virtual std::array<Scalar, 2> getRescalingFactorsTwo(uint64_t timestep, Scalar deltaT)
+        {
+        return {1.0, 1.0};
+        }
+    virtual void advanceThermostat(uint64_t timestep, Scalar deltaT) { }
+    void setT(Scalar T)
+        {
+        m_T = T;
+        }
+    Scalar getT() const
+        {
+        return m_T;
+        }
+
+    protected:
+    Scalar m_T;
+    std::shared_ptr<ParticleGroup> m_group;
+    std::shared_ptr<ComputeThermoGPU> m_thermo;
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    };
+
+//! hoomd/md/Thermostat.h:374-420
+class BerendsenThermostat : public Thermostat
+    {
+    public:
+    BerendsenThermostat(Scalar T, std::shared_ptr<ParticleGroup> group, std::shared_ptr<ComputeThermoGPU> thermo, std::shared_ptr<SystemDefinition> sysdef, Scalar tau)
+        : Thermostat(T, group, thermo, sysdef), m_tau(tau)
+        {
+        }
+    std::array<Scalar, 2> getRescalingFactorsOne(uint64_t timestep, Scalar deltaT) override;
+
+    private:
+    Scalar m_tau;
+    };
+
+//! hoomd/md/Thermostat.h:337-372.  The reference draws the Gamma variate from Philox (random123,
+//! not vendored); this class draws it from std::mt19937_64 seeded with (seed, timestep), so the
+//! ensemble is the same but the random stream is not (statistical parity only).
+class BussiThermostat : public Thermostat
+    {
+    public:
+    using Thermostat::Thermostat;
+    std::array<Scalar, 2> getRescalingFactorsOne(uint64_t timestep, Scalar deltaT) override;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Integration methods (hoomd/md/IntegrationMethodTwoStep.h, hoomd/md/TwoStepConstantVolume{,GPU}.*)
+// ---------------------------------------------------------------------------------------------
+class IntegrationMethodTwoStep
+    {
+    public:
+    IntegrationMethodTwoStep(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ParticleGroup> group)
+        : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_group(group)
+        {
+        }
+    virtual ~IntegrationMethodTwoStep() { }
+    virtual void integrateStepOne(uint64_t timestep) = 0;
+    virtual void integrateStepTwo(uint64_t timestep) = 0;
+    virtual bool isMomentumConserving() const
+        {
+        return true;
+        }
+    void setDeltaT(Scalar dt)
+        {
+        m_deltaT = dt;
+        }
+    std::shared_ptr<ParticleGroup> getGroup() const
+        {
+        return m_group;
+        }
+    //! hoomd/md/IntegrationMethodTwoStep.cc:73-108 (3 per member in 3D, 2 in 2D)
+    Scalar getTranslationalDOF(std::shared_ptr<ParticleGroup> query);
+
+    protected:
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<ParticleData> m_pdata;
+    std::shared_ptr<ParticleGroup> m_group;
+    Scalar m_deltaT = 0;
+    };
+
+class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
+    {
+    public:
+    TwoStepConstantVolumeGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ParticleGroup> group, std::shared_ptr<Thermostat> thermostat)
+        : IntegrationMethodTwoStep(sysdef, group), m_thermostat(thermostat)
+        {
+        }
+    void integrateStepOne(uint64_t timestep) override;
+    void integrateStepTwo(uint64_t timestep) override;
+    void setThermostat(std::shared_ptr<Thermostat> t)
+        {
+        m_thermostat = t;
+        }
+    //! maximum displacement per step; negative disables (hoomd/md/TwoStepConstantVolume.h:57-67)
+    void setLimit(Scalar l)
+        {
+        m_limit = l;
+        }
+    Scalar getLimit() const
+        {
+        return m_limit;
+        }
+
+    private:
+    std::shared_ptr<Thermostat> m_thermostat;
+    Scalar m_limit = -1;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// Integrator / IntegratorTwoStep (hoomd/Integrator.{h,cc}, hoomd/md/IntegratorTwoStep.{h,cc})
+// ---------------------------------------------------------------------------------------------
+class IntegratorTwoStep
+    {
+    public:
+    IntegratorTwoStep(std::shared_ptr<SystemDefinition> sysdef, Scalar deltaT);
+    ~IntegratorTwoStep();
+    void update(uint64_t timestep);
+    void prepRun(uint64_t timestep);
+    void setDeltaT(Scalar dt);
+    Scalar getDeltaT() const
+        {
+        return m_deltaT;
+        }
+    std::vector<std::shared_ptr<ForceCompute>>& getForces()
+        {
+        return m_forces;
+        }
+    std::vector<std::shared_ptr<IntegrationMethodTwoStep>>& getIntegrationMethods()
+        {
+        return m_methods;
+        }
+    void notifyForcesChanged()
+        {
+        m_prepared = false;
+        }
+    //! hoomd/md/IntegratorTwoStep.cc:161-196
+    Scalar getTranslationalDOF(std::shared_ptr<ParticleGroup> group);
+    void updateGroupDOF(std::shared_ptr<ParticleGroup> group)
+        {
+        group->setTranslationalDOF(getTranslationalDOF(group));
+        }
+    std::array<double, 3> computeLinearMomentum();
+    void computeNetForceGPU(uint64_t timestep);
+    //! pdata flags the integrator wants on a step (pressure_tensor when a consumer asked for it)
+    void setRequestPressure(bool b)
+        {
+        m_request_pressure = b;
+        }
+
+    private:
+    void computeAccelerations(uint64_t timestep);
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<ParticleData> m_pdata;
+    Scalar m_deltaT;
+    std::vector<std::shared_ptr<ForceCompute>> m_forces;
+    std::vector<std::shared_ptr<IntegrationMethodTwoStep>> m_methods;
+    bool m_prepared = false, m_request_pressure = false;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// ParticleSorter: periodic cell-order reordering (role of hoomd/SFCPackTuner{,GPU}.*)
+// ---------------------------------------------------------------------------------------------
+class ParticleSorter
+    {
+    public:
+    ParticleSorter(std::shared_ptr<SystemDefinition> sysdef, uint64_t period);
+    void setPeriod(uint64_t p)
+        {
+        m_period = p;
+        }
+    uint64_t getPeriod() const
+        {
+        return m_period;
+        }
+    //! cell width of the sorting grid (defaults to the neighbor-list cell width when one exists)
+    void setWidth(Scalar w)
+        {
+        m_width = w;
+        }
+    void update(uint64_t timestep);
+    void sortNow();
+
+    private:
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<ParticleData> m_pdata;
+    std::shared_ptr<CellListGPU> m_cl;
+    uint64_t m_period;
+    Scalar m_width = 0;
+    uint64_t m_last_sorted = (uint64_t)-1;
+    DeviceArray<unsigned int> m_order, m_offsets;
+    DeviceArray<unsigned char> m_workspace;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// System (hoomd/System.{h,cc}): the step loop
+// ---------------------------------------------------------------------------------------------
+class System
+    {
+    public:
+    System(std::shared_ptr<SystemDefinition> sysdef, uint64_t initial_tstep) : m_sysdef(sysdef), m_cur_tstep(initial_tstep) { }
+    void setIntegrator(std::shared_ptr<IntegratorTwoStep> i)
+        {
+        m_integrator = i;
+        }
+    std::shared_ptr<IntegratorTwoStep> getIntegrator() const
+        {
+        return m_integrator;
+        }
+    void setSorter(std::shared_ptr<ParticleSorter> s)
+        {
+        m_sorter = s;
+        }
+    void setPressureFlag(bool b)
+        {
+        m_pressure_flag = b;
+        }
+    void run(uint64_t nsteps);
+    uint64_t getCurrentTimeStep() const
+        {
+        return m_cur_tstep;
+        }
+    double getLastTPS() const
+        {
+        return m_last_tps;
+        }
+    double getLastWalltime() const
+        {
+        return m_last_walltime;
+        }
+
+    private:
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<IntegratorTwoStep> m_integrator;
+    std::shared_ptr<ParticleSorter> m_sorter;
+    uint64_t m_cur_tstep;
+    bool m_pressure_flag = false;
+    double m_last_tps = 0, m_last_walltime = 0;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// optional per-kernel timing with HIP events on the launch stream (bench harness)
+// ---------------------------------------------------------------------------------------------
+struct KernelTimer
+    {
+    static KernelTimer& get();
+    void enable(bool on);
+    bool enabled() const
+        {
+        return m_on;
+        }
+    void begin(const char* name);
+    void end(const char* name);
+    //! name -> (count, total ms); synchronizes the stream
+    std::vector<std::tuple<std::string, uint64_t, double>> collect();
+    void reset();
+
+    private:
+    bool m_on = false;
+    struct Rec
+        {
+        std::string name;
+        hipEvent_t e0, e1;
+        };
+    std::vector<Rec> m_open, m_done;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pool;
+    std::vector<std::tuple<std::string, uint64_t, double>> m_acc;
+    };
+
+struct ScopedKernelTimer
+    {
+    const char* n;
+    explicit ScopedKernelTimer(const char* name) : n(name)
+        {
+        if (KernelTimer::get().enabled())
+            KernelTimer::get().begin(n);
+        }
+    ~ScopedKernelTimer()
+        {
+        if (KernelTimer::get().enabled())
+            KernelTimer::get().end(n);
+        }
+    };
+
+    } // namespace hoomd_amd
+
+#endif

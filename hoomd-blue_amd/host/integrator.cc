@@ -1,0 +1,291 @@
+// integrator.cc -- TwoStepConstantVolumeGPU, IntegratorTwoStep, ParticleSorter and the System loop.
+// Follows hoomd/md/TwoStepConstantVolumeGPU.cc:46-110, hoomd/md/IntegratorTwoStep.cc:51-130,161-196,
+// 233-288, hoomd/Integrator.cc:106-158,344-560, hoomd/System.cc:80-190.
+#include "hoomd_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace hoomd_amd
+    {
+// hoomd/md/IntegrationMethodTwoStep.cc:73-108
+Scalar IntegrationMethodTwoStep::getTranslationalDOF(std::shared_ptr<ParticleGroup> query)
+    {
+    // members shared by the query group and the method's group
+    unsigned int n;
+    if (m_group->isAll())
+        n = query->getNumMembersGlobal();
+    else if (query->isAll())
+        n = m_group->getNumMembersGlobal();
+    else
+        n = std::min(query->getNumMembersGlobal(), m_group->getNumMembersGlobal());
+    return Scalar(m_sysdef->getNDimensions()) * Scalar(n);
+    }
+
+// hoomd/md/TwoStepConstantVolumeGPU.cc:46-82
+void TwoStepConstantVolumeGPU::integrateStepOne(uint64_t timestep)
+    {
+    if (m_group->getNumMembersGlobal() == 0)
+        throw std::runtime_error("Empty integration group.");
+    const auto rescale = m_thermostat ? m_thermostat->getRescalingFactorsOne(timestep, m_deltaT) : std::array<Scalar, 2> {1., 1.};
+    hmd_step_one_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_pos = m_pdata->pos();
+    a.d_vel = m_pdata->vel();
+    a.d_accel = m_pdata->accel();
+    a.d_image = m_pdata->image();
+    a.d_group_members = m_group->getIndexArray();
+    a.group_size = m_group->getNumMembers();
+    a.box = m_pdata->getBox().b;
+    a.rescale_factor = rescale[0];
+    a.deltaT = m_deltaT;
+    a.use_limit = m_limit >= 0;
+    a.maximum_displacement = m_limit;
+        {
+        ScopedKernelTimer t("step_one");
+        abiCheck(hmd_nvt_rescale_step_one(&a, nullptr), "hmd_nvt_rescale_step_one");
+        }
+    if (m_thermostat)
+        m_thermostat->advanceThermostat(timestep, m_deltaT);
+    }
+
+// hoomd/md/TwoStepConstantVolumeGPU.cc:84-110
+void TwoStepConstantVolumeGPU::integrateStepTwo(uint64_t timestep)
+    {
+    const auto rescale = m_thermostat ? m_thermostat->getRescalingFactorsTwo(timestep, m_deltaT) : std::array<Scalar, 2> {1., 1.};
+    hmd_step_two_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_vel = m_pdata->vel();
+    a.d_accel = m_pdata->accel();
+    a.d_group_members = m_group->getIndexArray();
+    a.group_size = m_group->getNumMembers();
+    a.d_net_force = m_pdata->netForceForIntegration();
+    a.deltaT = m_deltaT;
+    a.rescale_factor = rescale[0];
+    ScopedKernelTimer t("step_two");
+    abiCheck(hmd_nvt_rescale_step_two(&a, nullptr), "hmd_nvt_rescale_step_two");
+    }
+
+// ---------------------------------------------------------------------------------------------
+IntegratorTwoStep::IntegratorTwoStep(std::shared_ptr<SystemDefinition> sysdef, Scalar deltaT)
+    : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_deltaT(deltaT)
+    {
+    }
+
+IntegratorTwoStep::~IntegratorTwoStep()
+    {
+    m_pdata->aliasNetForce(nullptr);
+    }
+
+void IntegratorTwoStep::setDeltaT(Scalar dt)
+    {
+    m_deltaT = dt;
+    for (auto& m : m_methods)
+        m->setDeltaT(dt);
+    }
+
+// hoomd/md/IntegratorTwoStep.cc:161-196
+Scalar IntegratorTwoStep::getTranslationalDOF(std::shared_ptr<ParticleGroup> group)
+    {
+    Scalar removed = 0;
+    const unsigned int N_filter = group->getNumMembersGlobal();
+    const unsigned int N_particles = m_pdata->getNGlobal();
+    if (m_methods.size() == 1 && m_methods[0]->isMomentumConserving() && m_methods[0]->getGroup()->getNumMembersGlobal() == N_particles)
+        removed = Scalar(m_sysdef->getNDimensions()) * (Scalar(N_filter) / Scalar(N_particles));
+    Scalar total = 0;
+    for (auto& m : m_methods)
+        total += m->getTranslationalDOF(group);
+    return total - removed;
+    }
+
+// hoomd/Integrator.cc:131-158
+std::array<double, 3> IntegratorTwoStep::computeLinearMomentum()
+    {
+    const unsigned int n = m_pdata->getN();
+    std::vector<Scalar4> vel(n);
+    if (n)
+        hipCheck(hipMemcpy(vel.data(), m_pdata->vel(), sizeof(Scalar4) * n, hipMemcpyDeviceToHost), "vel D2H");
+    std::array<double, 3> p {{0, 0, 0}};
+    for (auto& v : vel)
+        {
+        p[0] += v.w * v.x;
+        p[1] += v.w * v.y;
+        p[2] += v.w * v.z;
+        }
+    return p;
+    }
+
+// hoomd/Integrator.cc:344-560.  With one force compute and no virial request the sum is the
+// identity: the integrator then reads that force array directly instead of copying it.
+void IntegratorTwoStep::computeNetForceGPU(uint64_t timestep)
+    {
+    for (auto& f : m_forces)
+        f->compute(timestep);
+
+    Scalar ext_e = 0, ext_v[6] = {0, 0, 0, 0, 0, 0};
+    for (auto& f : m_forces)
+        {
+        ext_e += f->getExternalEnergy();
+        for (unsigned int k = 0; k < 6; k++)
+            ext_v[k] += f->getExternalVirial(k);
+        }
+    m_pdata->setExternalEnergy(ext_e);
+    for (unsigned int k = 0; k < 6; k++)
+        m_pdata->setExternalVirial(k, ext_v[k]);
+
+    const bool virial = m_pdata->getFlag(pressure_tensor);
+    if (m_forces.size() == 1 && !virial)
+        {
+        m_pdata->aliasNetForce(m_forces[0]->getForceArray());
+        return;
+        }
+    m_pdata->aliasNetForce(nullptr);
+
+    const unsigned int nparticles = m_pdata->getN() + m_pdata->getNGhosts();
+    if (m_forces.empty())
+        {
+        hipCheck(hipMemsetAsync(m_pdata->netForce(), 0, sizeof(Scalar4) * nparticles, 0), "zero net force");
+        return;
+        }
+    ScopedKernelTimer t("sum_net_force");
+    for (size_t base = 0; base < m_forces.size(); base += 6)
+        {
+        hmd_sum_net_force_args_t a;
+        std::memset(&a, 0, sizeof(a));
+        a.d_net_force = m_pdata->netForce();
+        a.d_net_virial = m_pdata->netVirial();
+        a.net_virial_pitch = m_pdata->netVirialPitch();
+        for (size_t k = 0; k < 6 && base + k < m_forces.size(); k++)
+            {
+            a.force_list.f[k] = m_forces[base + k]->getForceArray();
+            a.force_list.v[k] = m_forces[base + k]->getVirialArray();
+            a.force_list.vpitch[k] = m_forces[base + k]->getVirialPitch();
+            }
+        a.nparticles = nparticles;
+        a.clear = (base == 0);
+        a.compute_virial = virial;
+        abiCheck(hmd_integrator_sum_net_force(&a, nullptr), "hmd_integrator_sum_net_force");
+        }
+    }
+
+void IntegratorTwoStep::computeAccelerations(uint64_t timestep)
+    {
+    abiCheck(hmd_compute_accelerations(m_pdata->accel(), m_pdata->vel(), m_pdata->netForceForIntegration(), m_pdata->getN(), nullptr),
+             "hmd_compute_accelerations");
+    }
+
+// hoomd/md/IntegratorTwoStep.cc:233-288
+void IntegratorTwoStep::prepRun(uint64_t timestep)
+    {
+    for (auto& m : m_methods)
+        m->setDeltaT(m_deltaT);
+    if (m_sysdef->isDomainDecomposed())
+        {
+        m_sysdef->getCommunicator()->forceMigrate();
+        m_sysdef->getCommunicator()->communicate(timestep);
+        }
+    computeNetForceGPU(timestep);
+    if (!m_pdata->isAccelSet())
+        {
+        computeAccelerations(timestep);
+        m_pdata->notifyAccelSet();
+        }
+    m_prepared = true;
+    }
+
+// hoomd/md/IntegratorTwoStep.cc:51-130
+void IntegratorTwoStep::update(uint64_t timestep)
+    {
+    if (!m_prepared)
+        prepRun(timestep);
+    for (auto& m : m_methods)
+        {
+        m->setDeltaT(m_deltaT);
+        m->integrateStepOne(timestep);
+        }
+    if (m_sysdef->isDomainDecomposed())
+        m_sysdef->getCommunicator()->communicate(timestep + 1);
+    computeNetForceGPU(timestep + 1);
+    for (auto it = m_methods.rbegin(); it != m_methods.rend(); ++it)
+        (*it)->integrateStepTwo(timestep);
+    }
+
+// ---------------------------------------------------------------------------------------------
+ParticleSorter::ParticleSorter(std::shared_ptr<SystemDefinition> sysdef, uint64_t period)
+    : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_cl(std::make_shared<CellListGPU>(sysdef)), m_period(period)
+    {
+    m_cl->setRadius(1);
+    m_cl->setFlagIndex();
+    }
+
+void ParticleSorter::update(uint64_t timestep)
+    {
+    if (m_period == 0 || timestep % m_period != 0 || timestep == m_last_sorted)
+        return;
+    m_last_sorted = timestep;
+    sortNow();
+    }
+
+void ParticleSorter::sortNow()
+    {
+    if (m_pdata->getN() == 0)
+        return;
+    // ghosts are dropped before reordering under domain decomposition: the communicator re-exchanges
+    // them on the forced rebuild that the sort signal triggers
+    if (m_width <= 0)
+        {
+        const auto npd = m_pdata->getBox().getNearestPlaneDistance();
+        const double rho = m_pdata->getN() / (m_pdata->getBox().getVolume(m_sysdef->getNDimensions() == 2));
+        m_width = std::max(std::cbrt(8.0 / std::max(rho, 1e-12)), std::min(npd[0], npd[1]) / 512.0);
+        }
+    m_cl->setNominalWidth(m_width);
+    m_cl->forceCompute(0);
+    const auto ci = m_cl->getCellIndexer();
+    const unsigned int ncells = ci.w * ci.h * ci.d;
+    m_order.resize(std::max(m_pdata->getMaxN(), 1u), false);
+    m_offsets.resize(ncells + 1, false);
+    m_workspace.resize(hmd_cell_order_workspace_bytes(ncells), false);
+    hmd_cell_order_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_order = m_order.get();
+    a.d_cell_offset = m_offsets.get();
+    a.d_cell_size = m_cl->getCellSizeArray().get();
+    a.d_cell_xyzf = m_cl->getXYZFArray().get();
+    a.ci = ci;
+    a.cli = m_cl->getCellListIndexer();
+    a.N = m_pdata->getN();
+    a.d_workspace = m_workspace.get();
+    a.workspace_bytes = m_workspace.size();
+        {
+        ScopedKernelTimer t("sorter");
+        abiCheck(hmd_cell_order(&a, nullptr), "hmd_cell_order");
+        m_pdata->applyOrder(m_order.get());
+        }
+    }
+
+// ---------------------------------------------------------------------------------------------
+// hoomd/System.cc:80-190
+void System::run(uint64_t nsteps)
+    {
+    if (!m_integrator)
+        throw std::runtime_error("Cannot run without an integrator");
+    auto pdata = m_sysdef->getParticleData();
+    pdata->setFlags(m_pressure_flag ? (1u << pressure_tensor) : 0u);
+    m_integrator->prepRun(m_cur_tstep);
+    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t s = 0; s < nsteps; s++)
+        {
+        if (m_sorter)
+            m_sorter->update(m_cur_tstep);
+        m_integrator->update(m_cur_tstep);
+        m_cur_tstep++;
+        }
+    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m_last_walltime = dt;
+    m_last_tps = (dt > 0 && nsteps > 0) ? double(nsteps) / dt : 0.0;
+    }
+
+    } // namespace hoomd_amd

@@ -1,0 +1,509 @@
+// neighbor_list.cc -- NeighborListGPUBinned host class: r_cut bookkeeping, the rebuild state
+// machine, head list / overflow protocol and exclusions.
+// Follows hoomd/md/NeighborList.cc:32-246 (construction), :363-435 (compute), :452-529 (updateRList),
+// :535-561 (checkBoxSize), :1313-1436 (needsUpdating + statistics), :1544-1625 (head list,
+// conditions), hoomd/md/NeighborListGPU.cc:29-232 and hoomd/md/NeighborListGPUBinned.cc:19-180.
+#include "hoomd_host.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace hoomd_amd
+    {
+NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> sysdef, Scalar r_buff)
+    : Compute(sysdef), m_cl(std::make_shared<CellListGPU>(sysdef)), m_r_buff(r_buff), m_h_words(64)
+    {
+    if (m_r_buff < 0.0)
+        throw std::runtime_error("Requested buffer radius is less than zero.");
+    const unsigned int nt = m_pdata->getNTypes();
+    m_r_cut.assign((size_t)nt * nt, 0.0);
+    m_rcut_max.assign(nt, 0.0);
+    m_Nmax.assign(nt, 4); // hoomd/md/NeighborList.cc:145-152
+    m_update_periods.assign(100, 0);
+    m_last_L = m_pdata->getGlobalBox().getNearestPlaneDistance();
+
+    m_d_Nmax.resize(nt);
+    m_d_Nmax.upload(m_Nmax.data(), nt);
+    m_conditions.resize(nt);
+    m_d_r_cut.resize((size_t)nt * nt);
+    m_d_rcut_max.resize(nt);
+    m_flag.resize(1);
+    m_req_size.resize(1);
+    reallocatePerParticle();
+    m_nlist.resize(4 * (size_t)std::max(m_pdata->getMaxN(), 1u), false);
+
+    // hoomd/md/NeighborListGPUBinned.cc:19-45
+    m_cl->setRadius(1);
+    m_cl->setComputeTypeBody(true);
+    m_cl->setFlagIndex();
+
+    m_sort_slot = m_pdata->getParticleSortSignal().connect([this]() { forceUpdate(); });
+    m_box_slot = m_pdata->getBoxChangeSignal().connect([this]() { forceUpdate(); });
+    m_maxn_slot = m_pdata->getMaxParticleNumberChangeSignal().connect([this]()
+                                                                      {
+                                                                      reallocatePerParticle();
+                                                                      forceUpdate();
+                                                                      });
+    }
+
+NeighborListGPUBinned::~NeighborListGPUBinned()
+    {
+    m_pdata->getParticleSortSignal().disconnect(m_sort_slot);
+    m_pdata->getBoxChangeSignal().disconnect(m_box_slot);
+    m_pdata->getMaxParticleNumberChangeSignal().disconnect(m_maxn_slot);
+    }
+
+void NeighborListGPUBinned::reallocatePerParticle()
+    {
+    const size_t n = std::max(m_pdata->getMaxN(), 1u);
+    m_n_neigh.resize(n, false);
+    m_head_list.resize(n, false);
+    m_last_pos.resize(n, false);
+    m_n_ex_idx.resize(n, false);
+    m_workspace.resize(hmd_nlist_head_list_workspace_bytes((unsigned int)n), false);
+    m_ex_dirty = true;
+    }
+
+void NeighborListGPUBinned::addRCutMatrix(std::shared_ptr<std::vector<Scalar>> m)
+    {
+    if (m->size() != m_r_cut.size())
+        throw std::invalid_argument("given r_cut_matrix is not the right size");
+    m_consumer_r_cut.push_back(m);
+    notifyRCutMatrixChange();
+    }
+
+void NeighborListGPUBinned::removeRCutMatrix(std::shared_ptr<std::vector<Scalar>> m)
+    {
+    m_consumer_r_cut.erase(std::remove(m_consumer_r_cut.begin(), m_consumer_r_cut.end(), m), m_consumer_r_cut.end());
+    notifyRCutMatrixChange();
+    }
+
+void NeighborListGPUBinned::setRBuff(Scalar r_buff)
+    {
+    m_r_buff = r_buff;
+    if (m_r_buff < 0.0)
+        throw std::runtime_error("Requested buffer radius is less than zero.");
+    notifyRCutMatrixChange();
+    forceUpdate();
+    }
+
+void NeighborListGPUBinned::setStorageMode(storageMode m)
+    {
+    m_storage_mode = m;
+    forceUpdate();
+    }
+
+void NeighborListGPUBinned::setDeterministic(bool d)
+    {
+    m_deterministic = d;
+    m_cl->setSortCellList(d);
+    forceUpdate();
+    }
+
+// hoomd/md/NeighborList.cc:452-529
+void NeighborListGPUBinned::updateRList()
+    {
+    const unsigned int nt = m_pdata->getNTypes();
+    std::fill(m_r_cut.begin(), m_r_cut.end(), 0.0);
+    for (auto& m : m_consumer_r_cut)
+        for (size_t i = 0; i < m_r_cut.size(); i++)
+            m_r_cut[i] = std::max(m_r_cut[i], (*m)[i]);
+    Scalar r_cut_max = 0.0;
+    for (unsigned int i = 0; i < nt; i++)
+        {
+        Scalar mi = 0.0;
+        for (unsigned int j = 0; j < nt; j++)
+            mi = std::max(mi, m_r_cut[j * nt + i]);
+        m_rcut_max[i] = mi;
+        r_cut_max = std::max(r_cut_max, mi);
+        }
+    m_rcut_max_max = r_cut_max;
+    Scalar r_cut_min = r_cut_max;
+    for (Scalar rc : m_r_cut)
+        if (rc > 0.0 && rc < r_cut_min)
+            r_cut_min = rc;
+    m_rcut_min = r_cut_min;
+    m_d_r_cut.upload(m_r_cut.data(), m_r_cut.size());
+    m_d_rcut_max.upload(m_rcut_max.data(), nt);
+    m_rcut_changed = false;
+    m_update_cell_size = true;
+    }
+
+// hoomd/md/NeighborList.cc:535-561
+void NeighborListGPUBinned::checkBoxSize()
+    {
+    const BoxDim& box = m_pdata->getBox();
+    const auto npd = box.getNearestPlaneDistance();
+    const Scalar rmax = m_rcut_max_max + m_r_buff;
+    if ((box.b.periodic[0] && npd[0] <= rmax * 2.0) || (box.b.periodic[1] && npd[1] <= rmax * 2.0)
+        || (m_sysdef->getNDimensions() == 3 && box.b.periodic[2] && npd[2] <= rmax * 2.0))
+        {
+        std::ostringstream oss;
+        oss << "nlist: Simulation box is too small, the neighbor list is searching beyond the minimum image: rmax=" << rmax;
+        throw std::runtime_error(oss.str());
+        }
+    }
+
+unsigned int NeighborListGPUBinned::getSmallestRebuild() const
+    {
+    for (unsigned int i = 0; i < m_update_periods.size(); i++)
+        if (m_update_periods[i] != 0)
+            return i;
+    return (unsigned int)m_update_periods.size();
+    }
+
+void NeighborListGPUBinned::resetStats()
+    {
+    m_updates = m_forced_updates = m_dangerous_updates = 0;
+    std::fill(m_update_periods.begin(), m_update_periods.end(), 0);
+    }
+
+// hoomd/md/NeighborListGPU.cc:29-101
+bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
+    {
+    const auto L_g = m_pdata->getGlobalBox().getNearestPlaneDistance();
+    hmd_nlist_check_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.lambda = Scalar3 {L_g[0] / m_last_L[0], L_g[1] / m_last_L[1], L_g[2] / m_last_L[2]};
+    a.lambda_min = std::min(a.lambda.x, std::min(a.lambda.y, a.lambda.z));
+    a.d_result = m_flag.get();
+    a.d_last_pos = m_last_pos.get();
+    a.d_pos = m_pdata->pos();
+    a.N = m_pdata->getN();
+    a.box = m_pdata->getBox().b;
+    a.d_rcut_max = m_d_rcut_max.get();
+    a.r_buff = m_r_buff;
+    a.ntypes = m_pdata->getNTypes();
+    a.checkn = ++m_checkn; // a fresh value each check: the flag never needs clearing
+    unsigned int* h = m_h_words.get();
+        {
+        ScopedKernelTimer t("nlist_check");
+        abiCheck(hmd_nlist_needs_update_check(&a, nullptr), "hmd_nlist_needs_update_check");
+        }
+    hipCheck(hipMemcpyAsync(h, m_flag.get(), sizeof(unsigned int), hipMemcpyDeviceToHost, 0), "flag D2H");
+    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    bool result = (h[0] == m_checkn);
+    if (m_sysdef->isDomainDecomposed())
+        result = m_sysdef->getCommunicator()->anyRank(result);
+    return result;
+    }
+
+// hoomd/md/NeighborList.cc:1325-1418
+bool NeighborListGPUBinned::needsUpdating(uint64_t timestep)
+    {
+    if (m_last_checked_tstep == timestep)
+        {
+        if (m_force_update)
+            {
+            m_force_update = false;
+            return true;
+            }
+        return m_last_check_result;
+        }
+    m_last_checked_tstep = timestep;
+
+    if (!m_force_update && timestep < (m_last_updated_tstep + m_rebuild_check_delay))
+        {
+        m_last_check_result = false;
+        return false;
+        }
+
+    bool result = false;
+    bool dangerous = m_dist_check && m_rebuild_check_delay > 1 && timestep == (m_last_updated_tstep + m_rebuild_check_delay);
+
+    if (m_force_update)
+        {
+        result = true;
+        m_force_update = false;
+        m_forced_updates += 1;
+        m_last_updated_tstep = timestep;
+        dangerous = false;
+        }
+    else
+        {
+        if (m_r_buff < 1e-6
+            || (!m_dist_check
+                && (m_rebuild_check_delay == 0 || (m_rebuild_check_delay > 1 && timestep == (m_last_updated_tstep + m_rebuild_check_delay)))))
+            result = true;
+        else
+            result = distanceCheck(timestep);
+
+        if (result)
+            {
+            if (timestep > m_last_updated_tstep)
+                {
+                uint64_t period = timestep - m_last_updated_tstep;
+                if (period >= m_update_periods.size())
+                    period = m_update_periods.size() - 1;
+                m_update_periods[period]++;
+                }
+            m_last_updated_tstep = timestep;
+            m_updates += 1;
+            }
+        }
+    if (result && dangerous)
+        m_dangerous_updates += 1;
+    m_last_check_result = result;
+    return result;
+    }
+
+// hoomd/md/NeighborListGPU.cc:166-232 / hoomd/md/NeighborList.cc:1544-1592
+void NeighborListGPUBinned::buildHeadList()
+    {
+    hmd_head_list_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_head_list = m_head_list.get();
+    a.d_req_size_nlist = m_req_size.get();
+    a.d_Nmax = m_d_Nmax.get();
+    a.d_pos = m_pdata->pos();
+    a.N = m_pdata->getN();
+    a.ntypes = m_pdata->getNTypes();
+    a.d_workspace = m_workspace.get();
+    a.workspace_bytes = m_workspace.size();
+    size_t req = 0;
+    if (a.ntypes == 1)
+        {
+        // uniform rows: the total is known without a readback
+        abiCheck(hmd_nlist_build_head_list(&a, nullptr), "hmd_nlist_build_head_list");
+        req = (size_t)a.N * m_Nmax[0];
+        }
+    else
+        {
+        abiCheck(hmd_nlist_build_head_list(&a, nullptr), "hmd_nlist_build_head_list");
+        hipCheck(hipMemcpy(&req, m_req_size.get(), sizeof(size_t), hipMemcpyDeviceToHost), "req size D2H");
+        }
+    resizeNlist(req);
+    }
+
+// hoomd/md/NeighborList.cc:1573-1592
+void NeighborListGPUBinned::resizeNlist(size_t size)
+    {
+    if (size > m_nlist.size())
+        {
+        size_t alloc = m_nlist.size() ? m_nlist.size() : 1;
+        while (size > alloc)
+            alloc = ((size_t)(((float)alloc) * 1.125f)) + 1;
+        alloc = (alloc > 4) ? (alloc + 3) & ~(size_t)3 : 4;
+        m_nlist.resize(alloc, false);
+        }
+    }
+
+// hoomd/md/NeighborList.cc:1601-1625
+bool NeighborListGPUBinned::checkConditions()
+    {
+    const unsigned int nt = m_pdata->getNTypes();
+    unsigned int* h = m_h_words.get();
+    hipCheck(hipMemcpyAsync(h, m_conditions.get(), sizeof(unsigned int) * nt, hipMemcpyDeviceToHost, 0), "conditions D2H");
+    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    bool result = false;
+    for (unsigned int i = 0; i < nt; i++)
+        if (h[i] > m_Nmax[i])
+            {
+            m_Nmax[i] = (h[i] > 4) ? (h[i] + 3) & ~3u : 4;
+            result = true;
+            }
+    if (result)
+        m_d_Nmax.upload(m_Nmax.data(), nt);
+    return result;
+    }
+
+void NeighborListGPUBinned::resetConditions()
+    {
+    m_conditions.zero();
+    }
+
+// hoomd/md/NeighborListGPUBinned.cc:49-180
+void NeighborListGPUBinned::buildNlist(uint64_t timestep)
+    {
+    if (m_storage_mode != full)
+        throw std::runtime_error("GPU neighbor lists require a full storage mode.");
+    if (m_update_cell_size)
+        {
+        m_cl->setNominalWidth(getMaxRCut() + m_r_buff);
+        m_update_cell_size = false;
+        }
+    m_cl->compute(timestep);
+
+    ScopedKernelTimer t("nlist_build");
+    hmd_nlist_binned_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_nlist = m_nlist.get();
+    a.d_n_neigh = m_n_neigh.get();
+    a.d_last_updated_pos = m_last_pos.get();
+    a.d_conditions = m_conditions.get();
+    a.d_Nmax = m_d_Nmax.get();
+    a.d_head_list = m_head_list.get();
+    a.d_pos = m_pdata->pos();
+    a.d_body = m_pdata->body();
+    a.N = m_pdata->getN();
+    a.d_cell_size = m_cl->getCellSizeArray().get();
+    a.d_cell_xyzf = m_cl->getXYZFArray().get();
+    a.d_cell_type_body = m_cl->getTypeBodyArray().get();
+    a.d_cell_adj = m_cl->getCellAdjArray().get();
+    a.ci = m_cl->getCellIndexer();
+    a.cli = m_cl->getCellListIndexer();
+    a.cadji = m_cl->getCellAdjIndexer();
+    a.box = m_pdata->getBox().b;
+    a.d_r_cut = m_d_r_cut.get();
+    a.r_buff = m_r_buff;
+    a.ntypes = m_pdata->getNTypes();
+    a.filter_body = m_filter_body;
+    a.ghost_width = m_cl->getGhostWidth();
+    abiCheck(hmd_compute_nlist_binned(&a, nullptr), "hmd_compute_nlist_binned");
+    }
+
+// hoomd/md/NeighborList.cc:363-435
+void NeighborListGPUBinned::compute(uint64_t timestep)
+    {
+    if (m_rcut_changed)
+        {
+        updateRList();
+        if (m_sysdef->isDomainDecomposed())
+            m_sysdef->getCommunicator()->communicate(timestep);
+        }
+    if (!shouldCompute(timestep) && !m_force_update)
+        return;
+
+    if (m_force_update)
+        {
+        buildHeadList();
+        if (m_exclusions_set)
+            updateExListIdx();
+        }
+
+    if (needsUpdating(timestep))
+        {
+        checkBoxSize();
+        bool overflowed = false;
+        do
+            {
+            buildNlist(timestep);
+            overflowed = checkConditions();
+            if (overflowed)
+                {
+                buildHeadList();
+                resetConditions();
+                }
+            } while (overflowed);
+
+        if (m_exclusions_set)
+            filterNlist();
+
+        // setLastUpdatedPos (hoomd/md/NeighborList.cc:1293-1311): the build kernel wrote last_pos
+        m_last_L = m_pdata->getGlobalBox().getNearestPlaneDistance();
+        m_has_been_updated_once = true;
+        }
+    }
+
+// ---- exclusions ------------------------------------------------------------------------------
+void NeighborListGPUBinned::clearExclusions()
+    {
+    m_ex_by_tag.clear();
+    m_n_exclusions = 0;
+    m_exclusions_set = false;
+    m_ex_dirty = true;
+    forceUpdate();
+    }
+
+// hoomd/md/NeighborList.cc:569-640: symmetric, duplicates ignored
+void NeighborListGPUBinned::addExclusion(unsigned int tag1, unsigned int tag2)
+    {
+    const unsigned int ng = m_pdata->getNGlobal();
+    if (tag1 >= ng || tag2 >= ng)
+        throw std::runtime_error("Particle tag out of bounds when attempting to add neighborlist exclusion");
+    if (m_ex_by_tag.size() < ng)
+        m_ex_by_tag.resize(ng);
+    auto& l1 = m_ex_by_tag[tag1];
+    if (std::find(l1.begin(), l1.end(), tag2) != l1.end())
+        return;
+    l1.push_back(tag2);
+    m_ex_by_tag[tag2].push_back(tag1);
+    m_n_exclusions++;
+    m_exclusions_set = true;
+    m_ex_dirty = true;
+    forceUpdate();
+    }
+
+// hoomd/md/NeighborListGPU.cc:132-163
+void NeighborListGPUBinned::updateExListIdx()
+    {
+    const unsigned int ng = m_pdata->getNGlobal();
+    if (m_ex_dirty)
+        {
+        unsigned int height = 1;
+        for (auto& l : m_ex_by_tag)
+            height = std::max<unsigned int>(height, (unsigned int)l.size());
+        m_ex_height = height;
+        std::vector<unsigned int> n_ex(ng, 0), list((size_t)ng * height, 0);
+        for (unsigned int t = 0; t < m_ex_by_tag.size(); t++)
+            {
+            n_ex[t] = (unsigned int)m_ex_by_tag[t].size();
+            for (unsigned int o = 0; o < n_ex[t]; o++)
+                list[(size_t)o * ng + t] = m_ex_by_tag[t][o];
+            }
+        m_n_ex_tag.resize(ng, false);
+        m_ex_list_tag.resize((size_t)ng * height, false);
+        m_n_ex_tag.upload(n_ex.data(), ng);
+        m_ex_list_tag.upload(list.data(), list.size());
+        m_ex_list_idx.resize((size_t)std::max(m_pdata->getMaxN(), 1u) * height, false);
+        m_ex_dirty = false;
+        }
+    hmd_update_exclusion_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_tag = m_pdata->tag();
+    a.d_rtag = m_pdata->rtag();
+    a.d_n_ex_tag = m_n_ex_tag.get();
+    a.d_ex_list_tag = m_ex_list_tag.get();
+    a.ex_list_tag_indexer = hmd_index2d_t {ng, m_ex_height};
+    a.d_n_ex_idx = m_n_ex_idx.get();
+    a.d_ex_list_idx = m_ex_list_idx.get();
+    a.ex_list_indexer = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
+    a.N = m_pdata->getN();
+    abiCheck(hmd_update_exclusion_list(&a, nullptr), "hmd_update_exclusion_list");
+    }
+
+void NeighborListGPUBinned::filterNlist()
+    {
+    ScopedKernelTimer t("nlist_filter");
+    hmd_nlist_filter_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_n_neigh = m_n_neigh.get();
+    a.d_nlist = m_nlist.get();
+    a.d_head_list = m_head_list.get();
+    a.d_n_ex = m_n_ex_idx.get();
+    a.d_ex_list = m_ex_list_idx.get();
+    a.exli = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
+    a.N = m_pdata->getN();
+    abiCheck(hmd_nlist_filter(&a, nullptr), "hmd_nlist_filter");
+    }
+
+// hoomd/md/NeighborList.cc:1726-1800 (getLocalPairList / getPairList)
+std::vector<std::pair<unsigned int, unsigned int>> NeighborListGPUBinned::getLocalPairList()
+    {
+    const unsigned int n = m_pdata->getN();
+    auto n_neigh = m_n_neigh.toHost(n);
+    auto head = m_head_list.toHost(n);
+    auto nlist = m_nlist.toHost();
+    std::vector<std::pair<unsigned int, unsigned int>> out;
+    for (unsigned int i = 0; i < n; i++)
+        for (unsigned int k = 0; k < n_neigh[i]; k++)
+            {
+            const unsigned int j = nlist[head[i] + k];
+            if (m_storage_mode == half || i < j)
+                out.emplace_back(i, j);
+            }
+    return out;
+    }
+
+std::vector<std::pair<unsigned int, unsigned int>> NeighborListGPUBinned::getPairList()
+    {
+    auto local = getLocalPairList();
+    auto tag = m_pdata->getN() + m_pdata->getNGhosts() ? std::vector<unsigned int>(m_pdata->getN() + m_pdata->getNGhosts()) : std::vector<unsigned int>();
+    if (!tag.empty())
+        hipCheck(hipMemcpy(tag.data(), m_pdata->tag(), sizeof(unsigned int) * tag.size(), hipMemcpyDeviceToHost), "tags D2H");
+    for (auto& p : local)
+        p = std::make_pair(tag[p.first], tag[p.second]);
+    return local;
+    }
+
+    } // namespace hoomd_amd

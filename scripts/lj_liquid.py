@@ -1,0 +1,48 @@
+"""LJ-liquid workload builder shared by bench.py and the tests: simple-cubic lattice at rho = 0.84,
+Gaussian velocities at kT = 1.5 (NumPy default_rng(1234)), zero net momentum."""
+import numpy as np
+
+
+def lattice(n, rho=0.84):
+    """n = (nx, ny, nz) lattice sites; returns positions (N,3) and box lengths."""
+    n = (n, n, n) if np.isscalar(n) else tuple(n)
+    a = (1.0 / rho) ** (1.0 / 3.0)
+    L = np.array(n, dtype=np.float64) * a
+    gx, gy, gz = [(np.arange(k) + 0.5) * a - l / 2 for k, l in zip(n, L)]
+    # x fastest in memory: neighbouring tags are neighbouring sites
+    z, y, x = np.meshgrid(gz, gy, gx, indexing="ij")
+    return np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1), L
+
+
+def velocities(N, kT=1.5, seed=1234):
+    rng = np.random.default_rng(seed)
+    v = rng.normal(0.0, np.sqrt(kT), (N, 3))
+    v -= v.mean(axis=0)
+    v *= np.sqrt(kT * 3 * (N - 1) / (v * v).sum())  # exactly kT on 3(N-1) degrees of freedom
+    return v
+
+
+def make_snapshot(hoomd, n, rho=0.84, kT=1.5, seed=1234):
+    pos, L = lattice(n, rho)
+    snap = hoomd.Snapshot()
+    snap.configuration.box = [L[0], L[1], L[2], 0, 0, 0]
+    snap.particles.N = len(pos)
+    snap.particles.types = ["A"]
+    snap.particles.position[:] = pos
+    snap.particles.velocity[:] = velocities(len(pos), kT, seed)
+    return snap
+
+
+def make_simulation(hoomd, n, rho=0.84, kT=1.5, r_cut=2.5, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200,
+                    decomposition=None, mode="none"):
+    dev = hoomd.device.GPU()
+    sim = hoomd.Simulation(device=dev, seed=seed)
+    sim.create_state_from_snapshot(make_snapshot(hoomd, n, rho, kT, seed), domain_decomposition=decomposition) if decomposition is not None \
+        else sim.create_state_from_snapshot(make_snapshot(hoomd, n, rho, kT, seed))
+    cell = hoomd.md.nlist.Cell(buffer=buffer)
+    lj = hoomd.md.pair.LJ(nlist=cell, default_r_cut=r_cut, mode=mode)
+    lj.params[("A", "A")] = dict(epsilon=1.0, sigma=1.0)
+    method = hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All(), thermostat=thermostat)
+    sim.operations.integrator = hoomd.md.Integrator(dt=dt, methods=[method], forces=[lj])
+    sim.operations.tuners[0].trigger = sorter_period
+    return sim, cell, lj, method
