@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LJ liquid, N = 1,048,576 particles per GPU (rho = 0.84, kT = 1.5, r_cut = 2.5,
+buffer = 0.4, dt = 0.005, fp64), cell list -> neighbor list -> LJ pair force -> velocity Verlet.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" is one MD time step of the whole system.  W untimed steps (the lattice is melted under a
+Berendsen thermostat, then switched to NVE), then exactly K NVE steps are timed between
+barrier + device synchronisation on both sides; the maximum over ranks is used.  With N > 1 GPUs the
+box is replicated per GPU (weak scaling) and split by spatial domain decomposition with a halo
+exchange over RCCL.  Rank 0 prints one JSON line.
+
+`value` is particle-steps per second of the whole job; `timesteps_per_s` rides along.
+`roofline` prices the pair-force kernel: algorithmic bytes per launch = 4 * (listed neighbors) +
+76 * N, divided by the kernel's average duration measured with HIP events on the launch stream
+inside the timed region.  `cpu_baseline` times the CPU oracle (a C restatement of the reference's
+CPU path: half neighbor list + Newton's third law) on one host core on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hoomd-blue_amd"), os.path.join(ROOT, "scripts")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def grid_for(n):
+    """Domain grid for n ranks: the split that keeps the per-GPU sub-box at 128 x 128 x 64 sites."""
+    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
+
+
+def cpu_baseline():
+    """Reference CPU path (oracle) on one core: 64 x 64 x 32 lattice (N = 131,072, same density,
+    temperature, cutoff and buffer), 40 NVE steps from the lattice start including every neighbor
+    list rebuild that the distance check triggers."""
+    import numpy as np
+    import lj_liquid
+    from oracle import oracle as orc
+
+    n = (64, 64, 32)
+    pos, L = lj_liquid.lattice(n)
+    N = len(pos)
+    vel = np.concatenate([lj_liquid.velocities(N), np.ones((N, 1))], axis=1)
+    sim = orc.Sim(orc.pack_pos(pos, np.zeros(N, dtype=int)), vel, L, r_cut=2.5, r_buff=0.4, dt=0.005)
+    sim.run(0)
+    steps = 40
+    t0 = time.perf_counter()
+    sim.run(steps)
+    dt = time.perf_counter() - t0
+    st = sim.stats()
+    return {
+        "value": N * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+        "sample": f"LJ liquid {n[0]}x{n[1]}x{n[2]} lattice (N={N}), {steps} NVE steps from the lattice start, "
+                  f"{st['num_builds']} neighbor-list rebuilds, {dt:.1f} s on one core; half list + third law",
+        "timesteps_per_s_at_sample_N": steps / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tpp", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import hoomd_amd as hoomd
+    from hoomd_amd import _hoomd_amd as cpp
+    import lj_liquid
+
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    decomposition = None
+    grid = grid_for(world)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        from hoomd_amd import comm
+        decomposition = comm.DomainDecomposition(grid=grid)
+
+    per_gpu = tuple(int(x) for x in args.lattice.split("x"))
+    n = tuple(a * g for a, g in zip(per_gpu, grid))
+    thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
+    sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
+    N_total = sim.state.N_particles
+    if args.tpp:
+        sim.run(0)
+        lj._cpp_obj.threads_per_particle = args.tpp
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up: melt under the thermostat (all but the last 200 steps), then NVE ----
+    melt = max(args.warmup - 200, 0) if args.warmup >= 400 else args.warmup // 2
+    sim.run(melt)
+    method.thermostat = None
+    sim.run(args.warmup - melt)
+
+    # ---- timed region ----
+    cell._cpp_obj.resetStats()
+    cpp.reset_kernel_timing()
+    cpp.enable_kernel_timing(True, "pair_force")
+    barrier()
+    t0 = time.perf_counter()
+    sim.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = cpp.kernel_timing()
+    cpp.enable_kernel_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # listed neighbors of this rank's particles (for the algorithmic byte count)
+    pdata = sim._sysdef.getParticleData()
+    n_local = pdata.N
+    import numpy as np
+    n_neigh = np.asarray(cell._cpp_obj.getNNeighArray(n_local), dtype=np.int64)
+    listed = int(n_neigh.sum())
+    calls, ms = timing.get("pair_force", (0, 0.0))
+    avg_s = (ms / 1e3 / calls) if calls else float("nan")
+    algo_bytes = 4.0 * listed + 76.0 * n_local
+    achieved = algo_bytes / avg_s / 1e9 if calls else float("nan")
+
+    if rank == 0:
+        out = {
+            "metric": "particle-steps/s (whole job) of the LJ-liquid short-range MD step; timesteps/s alongside",
+            "value": N_total * args.steps / elapsed,
+            "unit": "particle-steps/s",
+            "timesteps_per_s": args.steps / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
+                            "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64",
+                "N": N_total, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
+                "shortest_rebuild": int(cell.shortest_rebuild), "mean_listed_neighbors": listed / max(n_local, 1),
+            },
+            "roofline": {
+                "kernel": "pair_force_kernel<EvaluatorPairLJ> (rank 0)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

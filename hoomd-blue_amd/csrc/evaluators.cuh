@@ -19,16 +19,14 @@
 
 namespace hmd
     {
-// Reciprocal of a positive, finite double: hardware estimate refined by two Newton steps.
-// The second step leaves a relative error below 2^-52 for the inputs that occur here
-// (squared distances between 1e-3 and 1e4), far inside the 1e-6 force tolerance, at a third of
-// the instruction count of an IEEE-rounded division.
+// Reciprocal of a positive, finite double: the hardware estimate (v_rcp_f64, measured relative
+// error 4.6e-8 on MI355X) refined by one Newton step, which leaves 2.2e-15 (measured over 4M
+// inputs in [0.3, 9.3], scripts/exp/rcp_accuracy.hip) -- nine orders of magnitude inside the 1e-6
+// force tolerance, at a quarter of the instruction count of an IEEE-rounded division.
 __device__ __forceinline__ double fast_rcp(double x)
     {
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     }
 
 // 12-6 Lennard-Jones.  Formula and cutoff test as hoomd/md/EvaluatorPairLJ.h:162-211:

@@ -269,6 +269,18 @@ __global__ void __launch_bounds__(256) nlist_check_kernel(hmd_nlist_check_args_t
         atomicMax(a.d_result, a.checkn);
     }
 
+// Queued behind the check kernel: hands the flag to the host through pinned memory.  One 8-byte
+// system-scope store carries the flag and the caller's stamp together, so the polling host never
+// sees one without the other.
+__global__ void nlist_publish_kernel(const unsigned int* d_result, unsigned long long* d_published, unsigned int stamp)
+    {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        {
+        const unsigned long long v = ((unsigned long long)stamp << 32) | (unsigned long long)(*d_result);
+        __hip_atomic_store(d_published, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+
 // ---- head list: exclusive scan of Nmax[type_i] ----
 constexpr unsigned int HL_ITEMS = 8;
 constexpr unsigned int HL_BLOCK = 256;
@@ -462,13 +474,16 @@ extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, 
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_needs_update_check: args is NULL");
     HMD_REQUIRE(args->d_result && args->d_last_pos && args->d_pos && args->d_rcut_max, HMD_ERR_INVALID_ARGUMENT,
                 "hmd_nlist_needs_update_check: result, last_pos, pos and rcut_max are required");
-    if (args->N == 0)
-        return HMD_OK;
-    const dim3 grid(hmd_div_up(args->N, 256));
-    if (hmd_box_is_ortho(args->box))
-        hipLaunchKernelGGL((nlist_check_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *args);
-    else
-        hipLaunchKernelGGL((nlist_check_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, *args);
+    if (args->N != 0)
+        {
+        const dim3 grid(hmd_div_up(args->N, 256));
+        if (hmd_box_is_ortho(args->box))
+            hipLaunchKernelGGL((nlist_check_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, *args);
+        else
+            hipLaunchKernelGGL((nlist_check_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, *args);
+        }
+    if (args->d_published)
+        hipLaunchKernelGGL(nlist_publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, args->d_result, args->d_published, args->stamp);
     return hmd_launch_status();
     }
 

@@ -4,9 +4,11 @@
 // per-pair arithmetic order as hoomd/md/PotentialPair.h:660-752.  Results agree with the CPU path
 // to rounding (different summation order, fused multiply-adds allowed), well inside 1e-6 relative.
 //
-// Design: TPP lanes share one particle.  Each lane walks the particle's padded neighbor row with
-// stride TPP, so a wave reads 64/TPP rows in TPP*4-byte contiguous pieces, gathers pos[j] with two
-// 16-byte loads, and the partial sums are folded with TPP-wide butterfly shuffles.  Type-pair
+// Design: TPP lanes share one particle.  Per loop trip each lane takes FOUR consecutive entries of
+// the particle's padded neighbor row with one 16-byte load (the TPP lanes of a particle read
+// TPP*16 contiguous bytes), issues the four pos[j] gathers back to back so that eight 16-byte loads
+// are in flight per lane, prefetches the next trip's index slab, and only then evaluates the four
+// pairs.  The partial sums are folded with TPP-wide butterfly shuffles.  Type-pair
 // tables (params, r_cut^2, r_on^2) sit in LDS; with a single particle type they are wave-uniform
 // scalars and the type lookup disappears.  Workgroup ids are remapped so that each XCD walks a
 // contiguous range of particles: with the arrays in cell order its gathers stay inside one L2.
@@ -33,29 +35,47 @@ template<int TPP> __device__ __forceinline__ double pf_reduce(double v)
     return v;
     }
 
-// minimum image for the force loop: fused multiply-adds allowed (hoomd/BoxDim.h:306-325)
-template<bool ORTHO> __device__ __forceinline__ void pf_min_image(const hmd_box_t& b, double& x, double& y, double& z)
+// Box terms of the minimum-image step, hoisted out of the pair loop.  A non-periodic direction gets
+// Linv = 0, so its image count is rint(0) = 0 and no select is needed per pair.
+struct pf_box_t
     {
-    if (b.periodic[2])
-        {
-        const double img = rint(z * b.Linv[2]);
-        z -= b.L[2] * img;
-        if (!ORTHO)
-            {
-            y -= b.L[2] * b.yz * img;
-            x -= b.L[2] * b.xz * img;
-            }
-        }
-    if (b.periodic[1])
-        {
-        const double img = rint(y * b.Linv[1]);
-        y -= b.L[1] * img;
-        if (!ORTHO)
-            x -= b.L[1] * b.xy * img;
-        }
-    if (b.periodic[0])
-        x -= b.L[0] * rint(x * b.Linv[0]);
+    double Lx, Ly, Lz, Lix, Liy, Liz;
+    double Lz_yz, Lz_xz, Ly_xy;
+    };
+
+__device__ __forceinline__ pf_box_t pf_make_box(const hmd_box_t& b)
+    {
+    pf_box_t o;
+    o.Lx = b.L[0];
+    o.Ly = b.L[1];
+    o.Lz = b.L[2];
+    o.Lix = b.periodic[0] ? b.Linv[0] : 0.0;
+    o.Liy = b.periodic[1] ? b.Linv[1] : 0.0;
+    o.Liz = b.periodic[2] ? b.Linv[2] : 0.0;
+    o.Lz_yz = b.L[2] * b.yz;
+    o.Lz_xz = b.L[2] * b.xz;
+    o.Ly_xy = b.L[1] * b.xy;
+    return o;
     }
+
+// minimum image for the force loop (hoomd/BoxDim.h:306-325); fused multiply-adds allowed
+template<bool ORTHO> __device__ __forceinline__ void pf_min_image(const pf_box_t& b, double& x, double& y, double& z)
+    {
+    const double iz = rint(z * b.Liz);
+    z -= b.Lz * iz;
+    if (!ORTHO)
+        {
+        y -= b.Lz_yz * iz;
+        x -= b.Lz_xz * iz;
+        }
+    const double iy = rint(y * b.Liy);
+    y -= b.Ly * iy;
+    if (!ORTHO)
+        x -= b.Ly_xy * iy;
+    x -= b.Lx * rint(x * b.Lix);
+    }
+
+constexpr int PF_VEC = 4; // neighbors handled per lane per loop trip (one 16-byte index load)
 
 template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE, bool ORTHO>
 __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a, const typename Ev::param_type* d_params)
@@ -86,6 +106,7 @@ __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a,
             }
         __syncthreads();
         }
+    const pf_box_t box = pf_make_box(a.box);
 
     constexpr unsigned int PPB = PF_BLOCK / TPP; // particles per workgroup
     const unsigned int vb = pf_xcd_remap(blockIdx.x, gridDim.x);
@@ -104,80 +125,122 @@ __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a,
         double qi = 0.0;
         if (Ev::needsCharge())
             qi = a.d_charge[idx];
-        const unsigned int* row = a.d_nlist + a.d_head_list[idx];
+        const size_t head = a.d_head_list[idx];
+        const unsigned int* row = a.d_nlist + head;
+        // rows that start on a 16-byte boundary and are padded to a multiple of four entries (what the
+        // neighbor-list build produces) are read four indices at a time
+        const bool vec_ok = ((head & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.d_nlist) & 15) == 0) && (a.size_neigh_list >= head + ((nn + 3) & ~3u));
 
-#pragma unroll 4
-        for (unsigned int k = sub; k < nn; k += TPP)
-            {
-            const unsigned int j = row[k];
-            const double4 pj = hmd_ld4(a.d_pos + j);
-            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            pf_min_image<ORTHO>(a.box, dx, dy, dz);
-            const double rsq = dx * dx + dy * dy + dz * dz;
-
-            double rcutsq, ronsq = 0.0;
-            const param_t* prm;
-            if (SINGLE_TYPE)
+        auto load4 = [&](unsigned int k) -> uint4
+        {
+            uint4 v = make_uint4(idx, idx, idx, idx);
+            if (k < nn)
                 {
-                rcutsq = rcutsq0;
-                ronsq = ronsq0;
-                prm = &p0;
-                }
-            else
-                {
-                const unsigned int tp = hmd_double_as_uint(pj.w) * a.ntypes + ti;
-                rcutsq = s_rcutsq[tp];
-                if (SHIFT == 2)
-                    ronsq = s_ronsq[tp];
-                prm = s_params + tp;
-                }
-
-            bool energy_shift = false;
-            if (SHIFT == 1)
-                energy_shift = true;
-            else if (SHIFT == 2)
-                energy_shift = ronsq > rcutsq;
-
-            double fdr = 0.0, eng = 0.0;
-            Ev ev(rsq, rcutsq, *prm);
-            if (Ev::needsCharge())
-                ev.setCharge(qi, a.d_charge[j]);
-            const bool evaluated = ev.evalForceAndEnergy(fdr, eng, energy_shift);
-            if (!evaluated)
-                {
-                fdr = 0.0;
-                eng = 0.0;
-                }
-
-            if (SHIFT == 2)
-                {
-                if (evaluated && rsq >= ronsq && rsq < rcutsq)
+                if (vec_ok)
+                    v = *reinterpret_cast<const uint4*>(row + k);
+                else
                     {
-                    // XPLOR switching, hoomd/md/PotentialPair.h:711-737
-                    const double d3 = (rcutsq - ronsq) * (rcutsq - ronsq) * (rcutsq - ronsq);
-                    const double denom_inv = 1.0 / d3;
-                    const double d = rsq - rcutsq;
-                    const double sw = d * d * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * denom_inv;
-                    const double dsw = 12.0 * (rsq - ronsq) * d * denom_inv;
-                    fdr = sw * fdr - dsw * eng;
-                    eng = eng * sw;
+                    v.x = row[k];
+                    if (k + 1 < nn)
+                        v.y = row[k + 1];
+                    if (k + 2 < nn)
+                        v.z = row[k + 2];
+                    if (k + 3 < nn)
+                        v.w = row[k + 3];
                     }
                 }
+            return v;
+        };
 
-            fx += dx * fdr;
-            fy += dy * fdr;
-            fz += dz * fdr;
-            pe += eng;
-            if (VIRIAL)
+        uint4 cur = load4(sub * PF_VEC);
+        for (unsigned int k = sub * PF_VEC; k < nn; k += TPP * PF_VEC)
+            {
+            // index slab of the next trip: in flight while this trip's positions are gathered
+            const uint4 nxt = load4(k + TPP * PF_VEC);
+            unsigned int j[PF_VEC] = {cur.x, cur.y, cur.z, cur.w};
+            double4 pj[PF_VEC];
+#pragma unroll
+            for (int m = 0; m < PF_VEC; m++)
                 {
-                const double f2 = 0.5 * fdr;
-                vxx += dx * dx * f2;
-                vxy += dx * dy * f2;
-                vxz += dx * dz * f2;
-                vyy += dy * dy * f2;
-                vyz += dy * dz * f2;
-                vzz += dz * dz * f2;
+                // entries past the end of the row may hold anything: point them at the particle itself
+                j[m] = (k + m < nn) ? j[m] : idx;
+                pj[m] = hmd_ld4(a.d_pos + j[m]);
                 }
+#pragma unroll
+            for (int m = 0; m < PF_VEC; m++)
+                {
+                double dx = pi.x - pj[m].x, dy = pi.y - pj[m].y, dz = pi.z - pj[m].z;
+                pf_min_image<ORTHO>(box, dx, dy, dz);
+                const double rsq = dx * dx + dy * dy + dz * dz;
+
+                double rcutsq, ronsq = 0.0;
+                const param_t* prm;
+                if (SINGLE_TYPE)
+                    {
+                    rcutsq = rcutsq0;
+                    ronsq = ronsq0;
+                    prm = &p0;
+                    }
+                else
+                    {
+                    const unsigned int tp = hmd_double_as_uint(pj[m].w) * a.ntypes + ti;
+                    rcutsq = s_rcutsq[tp];
+                    if (SHIFT == 2)
+                        ronsq = s_ronsq[tp];
+                    prm = s_params + tp;
+                    }
+                // the padding entries (j == idx) sit at rsq = 0; disable them through the cutoff
+                if (k + m >= nn)
+                    rcutsq = -1.0;
+
+                bool energy_shift = false;
+                if (SHIFT == 1)
+                    energy_shift = true;
+                else if (SHIFT == 2)
+                    energy_shift = ronsq > rcutsq;
+
+                double fdr = 0.0, eng = 0.0;
+                Ev ev(rsq, rcutsq, *prm);
+                if (Ev::needsCharge())
+                    ev.setCharge(qi, a.d_charge[j[m]]);
+                const bool evaluated = ev.evalForceAndEnergy(fdr, eng, energy_shift);
+                if (!evaluated)
+                    {
+                    fdr = 0.0;
+                    eng = 0.0;
+                    }
+
+                if (SHIFT == 2)
+                    {
+                    if (evaluated && rsq >= ronsq && rsq < rcutsq)
+                        {
+                        // XPLOR switching, hoomd/md/PotentialPair.h:711-737
+                        const double d3 = (rcutsq - ronsq) * (rcutsq - ronsq) * (rcutsq - ronsq);
+                        const double denom_inv = 1.0 / d3;
+                        const double d = rsq - rcutsq;
+                        const double sw = d * d * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * denom_inv;
+                        const double dsw = 12.0 * (rsq - ronsq) * d * denom_inv;
+                        fdr = sw * fdr - dsw * eng;
+                        eng = eng * sw;
+                        }
+                    }
+
+                fx += dx * fdr;
+                fy += dy * fdr;
+                fz += dz * fdr;
+                pe += eng;
+                if (VIRIAL)
+                    {
+                    const double f2 = 0.5 * fdr;
+                    vxx += dx * dx * f2;
+                    vxy += dx * dy * f2;
+                    vxz += dx * dz * f2;
+                    vyy += dy * dy * f2;
+                    vyz += dy * dz * f2;
+                    vzz += dz * dz * f2;
+                    }
+                }
+            cur = nxt;
             }
         pe *= 0.5;
         }

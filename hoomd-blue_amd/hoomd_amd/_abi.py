@@ -75,7 +75,8 @@ class SortCellListArgs(C.Structure):
 
 class NlistCheckArgs(C.Structure):
     _fields_ = [("d_result", vp), ("d_last_pos", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_rcut_max", vp),
-                ("r_buff", f64), ("ntypes", u32), ("lambda_min", f64), ("lam", Scalar3), ("checkn", u32)]
+                ("r_buff", f64), ("ntypes", u32), ("lambda_min", f64), ("lam", Scalar3), ("checkn", u32),
+                ("d_published", vp), ("stamp", u32)]
 
 
 class HeadListArgs(C.Structure):

@@ -49,10 +49,15 @@ class Force:
     def virials(self):
         """(N, 6) virial contributions xx, xy, xz, yy, yz, zz (needs the pressure flag, as in
         hoomd/md/force.py:175-196: computed when a pressure consumer is attached)."""
-        self._ready("virials")
-        if not self._sim.always_compute_pressure:
-            return None
-        return np.asarray(self._cpp_obj.getVirials())
+        if self._cpp_obj is None:
+            raise DataAccessError("virials")
+        pdata = self._sim._sysdef.getParticleData()
+        flags = pdata.getFlags()
+        pdata.setFlags(flags | 1)  # pressure_tensor: forces are recomputed with the virial
+        self._cpp_obj.compute(self._sim.timestep)
+        v = np.asarray(self._cpp_obj.getVirials())
+        pdata.setFlags(flags)
+        return v
 
     @property
     def additional_energy(self):

@@ -132,9 +132,12 @@ class PinnedWords
         {
         return m_p;
         }
+    //! address of the same words as the device sees them
+    unsigned int* deviceView();
 
     private:
     unsigned int* m_p = nullptr;
+    unsigned int* m_d = nullptr;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1342,9 +1345,18 @@ struct KernelTimer
     {
     static KernelTimer& get();
     void enable(bool on);
+    //! time only the kernel with this name ("" = all)
+    void setFilter(const std::string& name)
+        {
+        m_filter = name;
+        }
     bool enabled() const
         {
         return m_on;
+        }
+    bool wants(const char* name) const
+        {
+        return m_on && (m_filter.empty() || m_filter == name);
         }
     void begin(const char* name);
     void end(const char* name);
@@ -1354,6 +1366,7 @@ struct KernelTimer
 
     private:
     bool m_on = false;
+    std::string m_filter;
     struct Rec
         {
         std::string name;
@@ -1367,14 +1380,15 @@ struct KernelTimer
 struct ScopedKernelTimer
     {
     const char* n;
-    explicit ScopedKernelTimer(const char* name) : n(name)
+    bool on;
+    explicit ScopedKernelTimer(const char* name) : n(name), on(KernelTimer::get().wants(name))
         {
-        if (KernelTimer::get().enabled())
+        if (on)
             KernelTimer::get().begin(n);
         }
     ~ScopedKernelTimer()
         {
-        if (KernelTimer::get().enabled())
+        if (on)
             KernelTimer::get().end(n);
         }
     };

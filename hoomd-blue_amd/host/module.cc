@@ -160,7 +160,12 @@ PYBIND11_MODULE(_hoomd_amd, m)
     m.def("synchronize", []() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); });
     m.def("abi_version", []() { return hmd_abi_version(); });
 
-    m.def("enable_kernel_timing", [](bool on) { KernelTimer::get().enable(on); });
+    m.def("enable_kernel_timing", [](bool on, const std::string& only)
+          {
+          KernelTimer::get().setFilter(only);
+          KernelTimer::get().enable(on);
+          },
+          py::arg("on"), py::arg("only") = "");
     m.def("reset_kernel_timing", []() { KernelTimer::get().reset(); });
     m.def("kernel_timing", []()
           {
@@ -200,6 +205,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("initializeFromSnapshot", [](ParticleData& p, py::dict d) { p.initializeFromSnapshot(make_snapshot(d)); })
         .def("applyOrder", [](ParticleData& p, uintptr_t d_order) { p.applyOrder((const unsigned int*)d_order); })
         .def("notifyParticleSort", &ParticleData::notifyParticleSort)
+        .def("getFlags", &ParticleData::getFlags)
+        .def("setFlags", &ParticleData::setFlags)
         .def_property_readonly("sort_count", &ParticleData::getSortCount)
         // raw device addresses for the Python-level halo exchange (wrapped as torch tensors there)
         .def_property_readonly("pos_ptr", [](ParticleData& p) { return (uintptr_t)p.pos(); })

@@ -175,14 +175,31 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
     a.r_buff = m_r_buff;
     a.ntypes = m_pdata->getNTypes();
     a.checkn = ++m_checkn; // a fresh value each check: the flag never needs clearing
-    unsigned int* h = m_h_words.get();
+    // the flag comes back through pinned memory that the host polls: no stream synchronisation,
+    // the GPU idles only for the PCIe write plus the launch of the next kernel
+    volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
+    a.d_published = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
+    a.stamp = m_checkn;
         {
         ScopedKernelTimer t("nlist_check");
         abiCheck(hmd_nlist_needs_update_check(&a, nullptr), "hmd_nlist_needs_update_check");
         }
-    hipCheck(hipMemcpyAsync(h, m_flag.get(), sizeof(unsigned int), hipMemcpyDeviceToHost, 0), "flag D2H");
-    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
-    bool result = (h[0] == m_checkn);
+    unsigned long long v = 0;
+    for (uint64_t spins = 0;; spins++)
+        {
+        v = *h;
+        if ((unsigned int)(v >> 32) == m_checkn)
+            break;
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff)
+            {
+            // surfaces a faulted kernel instead of spinning forever
+            hipError_t q = hipStreamQuery(0);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                hipCheck(q, "distance check");
+            }
+        }
+    bool result = ((unsigned int)v == m_checkn);
     if (m_sysdef->isDomainDecomposed())
         result = m_sysdef->getCommunicator()->anyRank(result);
     return result;

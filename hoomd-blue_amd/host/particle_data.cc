@@ -30,8 +30,15 @@ void abiCheck(int code, const char* what)
 
 PinnedWords::PinnedWords(size_t n)
     {
-    hipCheck(hipHostMalloc((void**)&m_p, n * sizeof(unsigned int), hipHostMallocDefault), "hipHostMalloc");
+    hipCheck(hipHostMalloc((void**)&m_p, n * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     std::memset(m_p, 0, n * sizeof(unsigned int));
+    }
+
+unsigned int* PinnedWords::deviceView()
+    {
+    if (!m_d)
+        hipCheck(hipHostGetDevicePointer((void**)&m_d, m_p, 0), "hipHostGetDevicePointer");
+    return m_d;
     }
 
 PinnedWords::~PinnedWords()

@@ -160,6 +160,13 @@ typedef struct
     double lambda_min;
     hmd_scalar3 lambda;
     unsigned int checkn;
+    /* Optional low-latency readback.  When d_published is not NULL (a device-visible address of
+       pinned host memory, hipHostGetDevicePointer), a one-lane kernel queued behind the check
+       stores ((uint64_t)stamp << 32) | *d_result there with a single system-scope 8-byte store;
+       the host can then poll that word instead of synchronising the stream (the reference reads
+       the flag back with a blocking copy, hoomd/md/NeighborListGPU.cc:77-82). */
+    unsigned long long* d_published;
+    unsigned int stamp;
     } hmd_nlist_check_args_t;
 int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream);
 
