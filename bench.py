@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpp", type=int, default=0)
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +94,10 @@ def main():
     grid = grid_for(world)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend=args.backend)
         from hoomd_amd import comm
         decomposition = comm.DomainDecomposition(grid=grid)
 

@@ -11,9 +11,17 @@ __version__ = "0.1.0"
 
 from . import _abi  # noqa: F401  (fails loudly when libhoomd_amd.so is missing)
 from . import _hoomd_amd  # noqa: F401  (fails loudly when the host module is missing)
-from . import device, error, filter, md, tune
+from . import device, error, filter, md, pair_plugin, tune
 from .box import Box
 from .simulation import Simulation
 from .snapshot import Snapshot
 
-__all__ = ["Box", "Simulation", "Snapshot", "device", "error", "filter", "md", "tune"]
+__all__ = ["Box", "Simulation", "Snapshot", "comm", "device", "error", "filter", "md", "pair_plugin", "tune"]
+
+
+def __getattr__(name):
+    # hoomd_amd.comm pulls in torch.distributed: loaded on first use only
+    if name == "comm":
+        import importlib
+        return importlib.import_module(".comm", __name__)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -771,6 +771,7 @@ class NeighborListGPUBinned : public Compute
     void forceUpdate()
         {
         m_force_update = true;
+        m_head_dirty = true;
         }
     uint64_t getNumUpdates() const
         {
@@ -856,6 +857,8 @@ class NeighborListGPUBinned : public Compute
 
     uint64_t m_updates = 0, m_forced_updates = 0, m_dangerous_updates = 0;
     bool m_force_update = true, m_dist_check = true, m_has_been_updated_once = false;
+    //! head list (and exclusion indices) are stale; survives a peekUpdate() that consumed m_force_update
+    bool m_head_dirty = true;
     uint64_t m_last_updated_tstep = 0, m_last_checked_tstep = 0, m_rebuild_check_delay = 0;
     bool m_last_check_result = false;
     std::vector<uint64_t> m_update_periods;

@@ -233,6 +233,8 @@ void ParticleSorter::sortNow()
         return;
     // ghosts are dropped before reordering under domain decomposition: the communicator re-exchanges
     // them on the forced rebuild that the sort signal triggers
+    if (m_sysdef->isDomainDecomposed())
+        m_pdata->setNGhosts(0);
     if (m_width <= 0)
         {
         const auto npd = m_pdata->getBox().getNearestPlaneDistance();

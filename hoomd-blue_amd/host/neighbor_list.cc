@@ -381,11 +381,12 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
     if (!shouldCompute(timestep) && !m_force_update)
         return;
 
-    if (m_force_update)
+    if (m_force_update || m_head_dirty)
         {
         buildHeadList();
         if (m_exclusions_set)
             updateExListIdx();
+        m_head_dirty = false;
         }
 
     if (needsUpdating(timestep))

@@ -164,8 +164,8 @@ void ParticleData::initializeFromSnapshot(const SnapshotParticleData& snap)
     const unsigned int n = snap.size;
     m_N = n;
     m_nghost = 0;
-    if (n > m_maxn)
-        reallocate(n);
+    if (n > m_maxn || m_maxn == 0)
+        reallocate(std::max(n, 64u));
     m_rtag.resize(std::max(m_nglobal, n), false);
 
     std::vector<Scalar4> pos(n), vel(n);

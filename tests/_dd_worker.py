@@ -1,0 +1,87 @@
+"""One rank of the GPU domain-decomposition test: `python _dd_worker.py RANK WORLD PORT GX GY GZ OUT`.
+All ranks share GPU 0; the process group is gloo (device buffers are staged through the host, which
+exercises everything except the RCCL transport itself).  Rank 0 writes the final global snapshot."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hoomd-blue_amd"), os.path.join(ROOT, "scripts"), HERE]
+
+import faulthandler
+import signal
+
+import torch
+import torch.distributed as dist
+
+faulthandler.register(signal.SIGUSR1, all_threads=True, chain=False)
+
+
+def build(hoomd, decomposition, n, steps, sorter):
+    import lj_liquid
+    snap = lj_liquid.make_snapshot(hoomd, n, kT=1.5, seed=11)
+    rng = np.random.default_rng(2)
+    snap.particles.position[:] += rng.normal(0, 0.05, snap.particles.position.shape)
+    snap.wrap()
+    sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=3)
+    if decomposition is None:
+        sim.create_state_from_snapshot(snap)
+    else:
+        sim.create_state_from_snapshot(snap, domain_decomposition=decomposition)
+    cell = hoomd.md.nlist.Cell(buffer=0.4)
+    lj = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.5, mode="shift")
+    lj.params[("A", "A")] = dict(epsilon=1.0, sigma=1.0)
+    method = hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All())
+    sim.operations.integrator = hoomd.md.Integrator(dt=0.005, methods=[method], forces=[lj])
+    if sorter:
+        sim.operations.tuners[0].trigger = 7
+    else:
+        sim.operations.tuners.clear()
+    thermo = hoomd.md.compute.ThermodynamicProperties(hoomd.filter.All())
+    sim.operations.computes.append(thermo)
+    return sim, cell, lj, thermo
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    grid = tuple(int(v) for v in sys.argv[4:7])
+    out = sys.argv[7]
+    n = tuple(int(v) for v in sys.argv[8:11])
+    steps = int(sys.argv[11])
+    sorter = bool(int(sys.argv[12]))
+    import hoomd_amd as hoomd
+    dd = None
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from hoomd_amd import comm
+        dd = comm.DomainDecomposition(grid=grid)
+    torch.cuda.set_device(0)
+    sim, cell, lj, thermo = build(hoomd, dd, n, steps, sorter)
+    sim.run(0)
+    e0 = (thermo.kinetic_energy, thermo.potential_energy)
+    sim.run(steps)
+    e1 = (thermo.kinetic_energy, thermo.potential_energy)
+    s = sim.state.get_snapshot()
+    dof = thermo.degrees_of_freedom  # collective under domain decomposition: every rank asks
+    stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds))
+    if dd is not None:
+        ex = dd.communicator.exchange
+        stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in))
+        allstats = [None] * world
+        dist.all_gather_object(allstats, stats)
+    else:
+        allstats = [stats]
+    if rank == 0:
+        np.savez(out, position=s.particles.position, velocity=s.particles.velocity, image=s.particles.image, e0=e0, e1=e1,
+                 dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
+                 builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats])
+    if dd is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,56 @@
+"""Multi-rank tests of the domain decomposition host logic on CPU tensors (gloo, world size 2 and 4):
+ownership, migration (including across the periodic boundary and to non-adjacent domains), the ghost
+layer against a brute-force expectation, forces from owned + ghost particles against the global
+minimum-image result, the per-step ghost update and the rebuild vote."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(script, world, extra, timeout=240, env=None):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, script), str(r), str(world), str(port)] + [str(e) for e in extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-4000:]}"
+    return outs
+
+
+@pytest.mark.parametrize("world,grid", [(2, (1, 1, 2)), (2, (2, 1, 1)), (4, (2, 2, 1)), (4, (0, 0, 0))])
+def test_migration_and_halo_exchange(world, grid):
+    launch("_comm_worker.py", world, grid)
+
+
+def test_grid_choice_minimises_surface():
+    """hoomd/DomainDecomposition.cc:327-408."""
+    from hoomd_amd import comm
+    assert comm.find_grid(8, [271.32, 271.32, 135.66]) == (2, 2, 2)
+    assert comm.find_grid(8, [100.0, 100.0, 100.0]) == (2, 2, 2)
+    assert comm.find_grid(2, [135.66, 135.66, 135.66 * 2]) == (1, 1, 2)
+    assert comm.find_grid(4, [10.0, 10.0, 40.0]) == (1, 1, 4)
+    assert comm.find_grid(4, [10.0, 10.0, 1.0], twod=True) == (2, 2, 1)
+    assert comm.find_grid(6, [30.0, 20.0, 10.0]) == (3, 2, 1)
+    assert comm.find_grid(1, [1.0, 1.0, 1.0]) == (1, 1, 1)
+    for n in (2, 3, 4, 6, 8, 12):
+        assert int(np.prod(comm.find_grid(n, [3.0, 2.0, 1.0]))) == n

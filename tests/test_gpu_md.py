@@ -342,3 +342,30 @@ def test_nan_and_out_of_box_are_reported(hoomd):
     sim2, _, _, _ = make_sim(hoomd, small)
     with pytest.raises(RuntimeError, match="too small"):
         sim2.run(0)
+
+
+@pytest.mark.parametrize("distance", np.linspace(0.1, 2.0, 3))
+@pytest.mark.parametrize("k", [0.5, 2.0, 5.0])
+@pytest.mark.parametrize("mode", ["none", "shift"])
+def test_example_plugin_force_and_energy(hoomd, distance, k, mode):
+    """example_plugins/pair_plugin/pytest/test_example_pair.py:15-81 (all three sigmas per case)."""
+    from hoomd_amd import pair_plugin
+    for sigma in (0.5, 1.0, 1.5):
+        sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=1)
+        sim.create_state_from_snapshot(two_particle_snapshot(hoomd, d=distance))
+        cell = hoomd.md.nlist.Cell(buffer=0.4)
+        ex = pair_plugin.pair.ExamplePair(cell, default_r_cut=sigma, mode=mode)
+        ex.params[("A", "A")] = dict(k=k, sigma=sigma)
+        sim.operations.integrator = hoomd.md.Integrator(dt=0.001, methods=[hoomd.md.methods.ConstantVolume(hoomd.filter.All())], forces=[ex])
+        sim.run(0)
+        snap = sim.state.get_snapshot()
+        dx = snap.particles.position[1] - snap.particles.position[0]
+        dr = np.linalg.norm(dx)
+        if dr >= sigma:
+            f, e = np.zeros(3), 0.0
+        else:
+            f = k * (sigma - dr) * dx / dr
+            e = 0.5 * k * (sigma - dr)**2  # the shift 0.5 k (r_cut - sigma)^2 vanishes at r_cut = sigma
+        np.testing.assert_array_almost_equal(ex.forces, [-f, f], decimal=6)
+        np.testing.assert_array_almost_equal(ex.energies, [e / 2, e / 2], decimal=6)
+        assert ex.params[("A", "A")] == dict(k=k, sigma=sigma)
