@@ -16,6 +16,7 @@
 
 #include "hoomd_amd.h"
 #include <hip/hip_runtime.h>
+#include <utility>
 
 namespace hmd
     {
@@ -63,8 +64,31 @@ class EvaluatorPairLJ
         return true;
         }
 
+    // Optional extension of the contract (detected by the kernels, not required from a plugin):
+    // force and energy without a branch for the unshifted potential.  Outside the cutoff rsq is
+    // replaced by 1e300, so r^-6 underflows to zero and both results vanish; eps = 0 gives
+    // lj1 = lj2 = 0 and zero results as well.
+    __device__ __forceinline__ void evalUnshiftedBranchFree(double& force_divr, double& pair_eng) const
+        {
+        const double x = (rsq < rcutsq) ? rsq : 1e300;
+        const double r2inv = fast_rcp(x);
+        const double r6inv = r2inv * r2inv * r2inv;
+        force_divr = r2inv * r6inv * (12.0 * lj1 * r6inv - 6.0 * lj2);
+        pair_eng = r6inv * (lj1 * r6inv - lj2);
+        }
+
     private:
     double rsq, rcutsq, lj1, lj2;
+    };
+
+// does the evaluator offer evalUnshiftedBranchFree()?
+template<class Ev, class = void> struct has_branch_free
+    {
+    static constexpr bool value = false;
+    };
+template<class Ev> struct has_branch_free<Ev, decltype(std::declval<const Ev&>().evalUnshiftedBranchFree(std::declval<double&>(), std::declval<double&>()))>
+    {
+    static constexpr bool value = true;
     };
 
 // Harmonic repulsion/attraction about sigma, the plugin example

@@ -18,7 +18,7 @@
 // Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
 // following sum (the CPU path rounds every product and sum separately).
 #pragma clang fp contract(off)
-#include "common.cuh"
+#include "tile.cuh"
 
 namespace
     {
@@ -45,19 +45,30 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
 
-template<bool SINGLE_TYPE, bool FILTER_BODY, bool ORTHO>
-__global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc)
+// MODE 0: minimum image per pair (any box); 1: the same for orthorhombic boxes; 2: the periodic image
+// of every adjacent cell is fixed up front (possible when each periodic direction has at least three
+// cells: the 3x3x3 stencil then never holds two images of one cell), so candidates are shifted once
+// when they are loaded and no minimum-image arithmetic (hoomd/BoxDim.h:306-325) runs per pair.
+// TILE (needs MODE 2): rows receive 16-bit candidate numbers of the 4x4x4-cell region around the home
+// cell's 2x2x2 block (tile.cuh) instead of particle indices, padded with 0xffff to a multiple of four.
+template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
+__global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
+                                                                unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
     unsigned int* s_excl_all = reinterpret_cast<unsigned int*>(s_raw);
     unsigned int* s_cell_all = s_excl_all + 64 * NL_WAVES;
-    double* s_rl2 = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
+    double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
+    unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * NL_WAVES);
+    double* s_rl2 = reinterpret_cast<double*>(s_tileoff_all + 64 * NL_WAVES);
 
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned int* s_excl = s_excl_all + 64 * wave;
     unsigned int* s_cell = s_cell_all + 64 * wave;
+    double* s_shift = s_shift_all + 3 * 64 * wave;
+    unsigned int* s_tileoff = s_tileoff_all + 64 * wave;
 
     if (!SINGLE_TYPE)
         {
@@ -108,6 +119,69 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
         }
     s_excl[lane] = incl - adj_size;
     s_cell[lane] = adj_cell;
+    if (MODE == 2)
+        {
+        // image of the adjacent cell seen from the home cell: its grid coordinate differs by -1, 0 or +1
+        // after unwrapping; r_image = r + ix*a1 + iy*a2 + iz*a3 (box vectors as in hoomd/BoxDim.h:391-458)
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (lane < n_adj)
+            {
+            const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
+            const int hc[3] = {(int)(cell % a.ci.w), (int)((cell / a.ci.w) % a.ci.h), (int)(cell / (a.ci.w * a.ci.h))};
+            const int ac[3] = {(int)(adj_cell % a.ci.w), (int)((adj_cell / a.ci.w) % a.ci.h), (int)(adj_cell / (a.ci.w * a.ci.h))};
+            double img[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                {
+                const int diff = ac[d] - hc[d];
+                img[d] = (a.box.periodic[d] && dim[d] >= 3) ? (diff > 1 ? -1.0 : (diff < -1 ? 1.0 : 0.0)) : 0.0;
+                }
+            sx = img[0] * a.box.L[0] + img[1] * (a.box.L[1] * a.box.xy) + img[2] * (a.box.L[2] * a.box.xz);
+            sy = img[1] * a.box.L[1] + img[2] * (a.box.L[2] * a.box.yz);
+            sz = img[2] * a.box.L[2];
+            }
+        s_shift[3 * lane + 0] = sx;
+        s_shift[3 * lane + 1] = sy;
+        s_shift[3 * lane + 2] = sz;
+        }
+    if (TILE)
+        {
+        const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
+        const int hc[3] = {(int)(cell % a.ci.w), (int)((cell / a.ci.w) % a.ci.h), (int)(cell / (a.ci.w * a.ci.h))};
+        const int c0[3] = {hc[0] & ~1, hc[1] & ~1, hc[2] & ~1};
+        int rimg[3];
+        const int rcell = hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg);
+        const unsigned int rsize = rcell >= 0 ? min(a.d_cell_size[rcell], a.cli.w) : 0u;
+        const unsigned int rincl = hmd::tile_wave_scan(rsize, (int)lane);
+        // d_tile_overflow[0]: a region outgrew the tile; [1]: largest region population seen (what the
+        // consumers of these rows need as LDS capacity)
+        const unsigned int rtotal = rl_u(rincl, 63);
+        if (rtotal > tile_capacity)
+            {
+            if (lane == 0)
+                d_tile_overflow[0] = 1u;
+            return;
+            }
+        if (lane == 0 && sub == 0 && rtotal > d_tile_overflow[1])
+            atomicMax(d_tile_overflow + 1, rtotal);
+        // region cell of each adjacent cell: home position in the block + unwrapped offset + 1
+        unsigned int rc = 0;
+        if (lane < n_adj)
+            {
+            const int ac[3] = {(int)(adj_cell % a.ci.w), (int)((adj_cell / a.ci.w) % a.ci.h), (int)(adj_cell / (a.ci.w * a.ci.h))};
+            int r[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                {
+                int diff = ac[d] - hc[d];
+                if (a.box.periodic[d])
+                    diff = diff > 1 ? diff - dim[d] : (diff < -1 ? diff + dim[d] : diff);
+                r[d] = min(max(hc[d] - c0[d] + diff + 1, 0), 3);
+                }
+            rc = (unsigned int)((r[2] * 4 + r[1]) * 4 + r[0]);
+            }
+        s_tileoff[lane] = __shfl(rincl - rsize, (int)rc);
+        }
     const unsigned int T = rl_u(incl, 63);
     // (single wave reads back its own LDS words: no workgroup barrier needed, only the wait
     //  for the ds_write the compiler inserts before the first dependent ds_read)
@@ -145,7 +219,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
             {
             const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(NL_MAXK * 64)));
             double cx[NL_MAXK], cy[NL_MAXK], cz[NL_MAXK];
-            unsigned int cj[NL_MAXK], ct[NL_MAXK], cb[NL_MAXK];
+            unsigned int cj[NL_MAXK], ct[NL_MAXK], cb[NL_MAXK], cl[NL_MAXK];
 #pragma unroll
             for (int c = 0; c < NL_MAXK; c++)
                 {
@@ -172,7 +246,15 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
                         cx[c] = v.x;
                         cy[c] = v.y;
                         cz[c] = v.z;
+                        if (MODE == 2)
+                            {
+                            cx[c] = HMD_ADD(cx[c], s_shift[3 * lo + 0]);
+                            cy[c] = HMD_ADD(cy[c], s_shift[3 * lo + 1]);
+                            cz[c] = HMD_ADD(cz[c], s_shift[3 * lo + 2]);
+                            }
                         cj[c] = hmd_double_as_uint(v.w);
+                        if (TILE)
+                            cl[c] = s_tileoff[lo] + (k - s_excl[lo]);
                         if (!SINGLE_TYPE || FILTER_BODY)
                             {
                             const uint2 tb = *reinterpret_cast<const uint2*>(a.d_cell_type_body + w);
@@ -208,7 +290,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
                         double dx = HMD_SUB(pix, cx[c]);
                         double dy = HMD_SUB(piy, cy[c]);
                         double dz = HMD_SUB(piz, cz[c]);
-                        hmd_min_image<ORTHO>(a.box, dx, dy, dz);
+                        if (MODE != 2)
+                            hmd_min_image<MODE == 1>(a.box, dx, dy, dz);
                         const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz));
                         const double rl2 = SINGLE_TYPE ? rl2_single : s_rl2[hmd_idx2(hmd_index2d_t {a.ntypes, a.ntypes}, ti, ct[c])];
                         bool hit = (rsq <= rl2) && (cj[c] != i_idx);
@@ -219,7 +302,12 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
                             {
                             const unsigned int pos = cnt_i + hmd_rank_in_mask(mask);
                             if (hit && pos < nmax_i)
-                                row[pos] = cj[c];
+                                {
+                                if (TILE)
+                                    (d_tile + head_i)[pos] = (unsigned short)cl[c];
+                                else
+                                    row[pos] = cj[c];
+                                }
                             cnt_i += (unsigned int)__popcll(mask);
                             }
                         }
@@ -233,6 +321,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
         if (lane < nh && hidx < a.N && (lane % wpc) == sub)
             {
             a.d_n_neigh[hidx] = cnt;
+            if (TILE)
+                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < hnmax; k++)
+                    (d_tile + hhead)[k] = 0xffffu;
             if (a.d_last_updated_pos)
                 {
                 // same bits as pos[hidx]: the cell list holds a copy of x,y,z and of the type id
@@ -417,15 +508,50 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
     }
 
 template<bool ST, bool FB>
-int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s)
+int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
+                 unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr)
     {
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const dim3 grid(hmd_div_up(ncells, cells_per_block));
-    if (hmd_box_is_ortho(a.box))
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc);
+    // fixed images need a radius-1 stencil in 3D whose cells are distinct along every periodic direction
+    const unsigned int dim[3] = {a.ci.w, a.ci.h, a.ci.d};
+    bool fixed_images = a.cadji.w == 27;
+    for (int d = 0; d < 3; d++)
+        if (a.box.periodic[d] && dim[d] < 3)
+            fixed_images = false;
+    if (d_tile)
+        {
+        HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow);
+        }
+    else if (fixed_images)
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
+    else if (hmd_box_is_ortho(a.box))
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
     else
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
     return hmd_launch_status();
+    }
+
+int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow)
+    {
+    const bool single = (a.ntypes == 1);
+    const bool fb = a.filter_body != 0;
+    const unsigned int ncells = a.ci.w * a.ci.h * a.ci.d;
+    // waves per cell: one fills the chip once there are several cells per SIMD slot
+    unsigned int wpc = 1;
+    if (ncells < 8192)
+        wpc = 2;
+    if (ncells < 2048)
+        wpc = 4;
+    const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
+    if (single && !fb)
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+    if (single && fb)
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+    if (!single && !fb)
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
     }
     } // namespace
 
@@ -452,21 +578,50 @@ extern "C" int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, voi
     if (a.N == 0)
         return HMD_OK;
 
-    // waves per cell: one fills the chip once there are several cells per SIMD slot
-    unsigned int wpc = 1;
-    if (ncells < 8192)
-        wpc = 2;
-    if (ncells < 2048)
-        wpc = 4;
-    const size_t lds = sizeof(unsigned int) * 128 * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
-    hipStream_t s = (hipStream_t)stream;
-    if (single && !fb)
-        return launch_nlist<true, false>(a, ncells, wpc, lds, s);
-    if (single && fb)
-        return launch_nlist<true, true>(a, ncells, wpc, lds, s);
-    if (!single && !fb)
-        return launch_nlist<false, false>(a, ncells, wpc, lds, s);
-    return launch_nlist<false, true>(a, ncells, wpc, lds, s);
+    return nlist_binned_driver(a, (hipStream_t)stream, nullptr, 0u, nullptr);
+    }
+
+// Tile rows from the same kernel (declared with the tile path in the header).
+extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_tiles: args is NULL");
+    const hmd_nlist_tiles_args_t& t = *args;
+    HMD_REQUIRE(t.geom.d_cell_size && t.geom.d_cell_idx && t.d_cell_xyzf && t.d_cell_adj && t.d_tile_nlist && t.d_n_neigh && t.d_conditions
+                    && t.d_Nmax && t.d_head_list && t.d_pos && t.d_r_cut && t.d_tile_overflow,
+                HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_tiles: a required array is NULL");
+    HMD_REQUIRE(t.ntypes == 1 || t.d_cell_type_body, HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_tiles: d_cell_type_body is required with more than one type");
+    unsigned int cap = 0;
+    const int rc = hmd_nlist_tiles_supported(&t.geom.ci, &t.box, t.geom.cli.w, t.ntypes, &cap);
+    if (rc != HMD_OK)
+        return rc;
+    HMD_REQUIRE(t.geom.capacity >= 1 && t.geom.capacity <= cap, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_tiles: geom.capacity must be in [1, 64 * cli.w]");
+    const unsigned int ncells = t.geom.ci.w * t.geom.ci.h * t.geom.ci.d;
+    HMD_REQUIRE(ncells > 0 && t.geom.cli.h == ncells && t.cadji.h == ncells && t.cadji.w == 27, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_tiles: indexers disagree on the number of cells, or the stencil is not 27 cells");
+    if (t.N == 0)
+        return HMD_OK;
+    hmd_nlist_binned_args_t a;
+    a = hmd_nlist_binned_args_t {};
+    a.d_n_neigh = t.d_n_neigh;
+    a.d_last_updated_pos = t.d_last_updated_pos;
+    a.d_conditions = t.d_conditions;
+    a.d_Nmax = t.d_Nmax;
+    a.d_head_list = t.d_head_list;
+    a.d_pos = t.d_pos;
+    a.N = t.N;
+    a.d_cell_size = t.geom.d_cell_size;
+    a.d_cell_xyzf = t.d_cell_xyzf;
+    a.d_cell_type_body = t.d_cell_type_body;
+    a.d_cell_adj = t.d_cell_adj;
+    a.ci = t.geom.ci;
+    a.cli = t.geom.cli;
+    a.cadji = t.cadji;
+    a.box = t.box;
+    a.d_r_cut = t.d_r_cut;
+    a.r_buff = t.r_buff;
+    a.ntypes = t.ntypes;
+    return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow);
     }
 
 extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream)

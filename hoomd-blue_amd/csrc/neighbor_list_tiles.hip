@@ -1,0 +1,90 @@
+// neighbor_list_tiles.hip -- limits of the tile path and expansion of tile rows (16-bit region-local
+// candidate numbers, see tile.cuh) into the particle-index rows of the reference layout
+// (hoomd/md/NeighborList.h:662-739).  The tile rows themselves are written by the binned build in
+// neighbor_list.hip.
+#pragma clang fp contract(off)
+#include "tile.cuh"
+
+namespace
+    {
+using namespace hmd;
+
+__global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_rows_args_t a)
+    {
+    __shared__ tile_tables T;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    unsigned int* tidx = reinterpret_cast<unsigned int*>(s_dyn);
+    int cx0, cy0, cz0;
+    tile_setup(a.geom, a.box, T, cx0, cy0, cz0);
+    __syncthreads();
+    if (T.off[TL_RC] > a.geom.capacity)
+        return;
+    tile_stage<false, true, false>(a.geom, a.box, T, nullptr, nullptr, nullptr, nullptr, tidx, nullptr);
+    __syncthreads();
+    const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    for (unsigned int hc = 0; hc < 8; hc++)
+        {
+        const int hx = hc & 1, hy = (hc >> 1) & 1, hz = hc >> 2;
+        if (!tile_is_home(a.geom, cx0, cy0, cz0, hx, hy, hz))
+            continue;
+        const unsigned int rc_home = ((hz + 1) * 4 + (hy + 1)) * 4 + (hx + 1);
+        for (unsigned int lh = T.off[rc_home] + wave; lh < T.off[rc_home + 1]; lh += 4)
+            {
+            const unsigned int i = tidx[lh];
+            if (i >= a.N)
+                continue;
+            const unsigned int n = a.d_n_neigh[i];
+            const size_t head = a.d_head_list[i];
+            for (unsigned int k = lane; k < n; k += 64)
+                a.d_nlist[head + k] = tidx[a.d_tile_nlist[head + k]];
+            }
+        }
+    }
+
+size_t build_lds_bytes(unsigned int cap, unsigned int ntypes)
+    {
+    size_t b = (size_t)cap * 24 + ((size_t)cap + (cap & 1)) * 4;
+    if (ntypes > 1)
+        b += (size_t)ntypes * ntypes * 8 + cap;
+    return (b + 15) / 16 * 16;
+    }
+    } // namespace
+
+extern "C" int hmd_nlist_tiles_supported(const hmd_index3d_t* ci, const hmd_box_t* box, unsigned int cell_Nmax, unsigned int ntypes,
+                                         unsigned int* capacity_out)
+    {
+    HMD_REQUIRE(ci && box && capacity_out, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_supported: ci, box and capacity_out are required");
+    const unsigned int dim[3] = {ci->w, ci->h, ci->d};
+    for (int d = 0; d < 3; d++)
+        {
+        HMD_REQUIRE(dim[d] >= 1, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_supported: empty cell grid");
+        HMD_REQUIRE(!box->periodic[d] || dim[d] >= 3, HMD_ERR_UNSUPPORTED,
+                    "tile path needs at least 3 cells along every periodic direction");
+        }
+    HMD_REQUIRE(ntypes >= 1 && ntypes <= 256, HMD_ERR_UNSUPPORTED, "tile path stores type ids in one byte");
+    const size_t cap = (size_t)hmd::TL_RC * cell_Nmax;
+    HMD_REQUIRE(cap >= 1 && cap <= 65535 && build_lds_bytes((unsigned int)cap, ntypes) <= hmd::TL_MAX_LDS, HMD_ERR_UNSUPPORTED,
+                "tile path: 64 cells of this occupancy do not fit the LDS tile");
+    *capacity_out = (unsigned int)cap;
+    return HMD_OK;
+    }
+
+extern "C" int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_to_rows: args is NULL");
+    const hmd_tiles_to_rows_args_t& a = *args;
+    HMD_REQUIRE(a.geom.d_cell_size && a.geom.d_cell_idx && a.d_tile_nlist && a.d_n_neigh && a.d_head_list && a.d_nlist,
+                HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_to_rows: a required array is NULL");
+    unsigned int cap = 0;
+    const int rc = hmd_nlist_tiles_supported(&a.geom.ci, &a.box, a.geom.cli.w, 1, &cap);
+    if (rc != HMD_OK)
+        return rc;
+    HMD_REQUIRE(a.geom.capacity >= 1 && a.geom.capacity <= cap, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_tiles_to_rows: geom.capacity must be in [1, 64 * cli.w]");
+    if (a.N == 0)
+        return HMD_OK;
+    const size_t lds = ((size_t)a.geom.capacity * 4 + 15) / 16 * 16;
+    hmd::tile_allow_big_lds(tiles_to_rows_kernel, lds);
+    hipLaunchKernelGGL(tiles_to_rows_kernel, dim3(hmd::tile_num_blocks(a.geom.ci)), dim3(hmd::TL_THREADS), lds, (hipStream_t)stream, a);
+    return hmd_launch_status();
+    }

@@ -16,6 +16,7 @@
 #define HMD_PAIR_FORCE_CUH
 
 #include "common.cuh"
+#include "evaluators.cuh"
 
 namespace hmd
     {
@@ -75,6 +76,96 @@ template<bool ORTHO> __device__ __forceinline__ void pf_min_image(const pf_box_t
     x -= b.Lx * rint(x * b.Lix);
     }
 
+// running sums of one lane
+struct pf_accum
+    {
+    double fx = 0, fy = 0, fz = 0, pe = 0;
+    double vxx = 0, vxy = 0, vxz = 0, vyy = 0, vyz = 0, vzz = 0;
+    };
+
+// One pair: evaluator, energy shift / XPLOR switching and accumulation
+// (hoomd/md/PotentialPair.h:660-752, hoomd/md/PotentialPairGPU.cuh:300-372).
+template<class Ev, unsigned int SHIFT, bool VIRIAL>
+__device__ __forceinline__ void pf_pair(pf_accum& s, double dx, double dy, double dz, double rcutsq, double ronsq,
+                                        const typename Ev::param_type& prm, double qi, double qj)
+    {
+    const double rsq = dx * dx + dy * dy + dz * dz;
+    bool energy_shift = false;
+    if (SHIFT == 1)
+        energy_shift = true;
+    else if (SHIFT == 2)
+        energy_shift = ronsq > rcutsq;
+
+    double fdr = 0.0, eng = 0.0;
+    Ev ev(rsq, rcutsq, prm);
+    if (Ev::needsCharge())
+        ev.setCharge(qi, qj);
+    bool evaluated = true;
+    if constexpr (SHIFT == 0 && has_branch_free<Ev>::value)
+        ev.evalUnshiftedBranchFree(fdr, eng);
+    else
+        {
+        evaluated = ev.evalForceAndEnergy(fdr, eng, energy_shift);
+        if (!evaluated)
+            {
+            fdr = 0.0;
+            eng = 0.0;
+            }
+        }
+    if (SHIFT == 2)
+        {
+        if (evaluated && rsq >= ronsq && rsq < rcutsq)
+            {
+            // XPLOR switching, hoomd/md/PotentialPair.h:711-737
+            const double d3 = (rcutsq - ronsq) * (rcutsq - ronsq) * (rcutsq - ronsq);
+            const double denom_inv = 1.0 / d3;
+            const double d = rsq - rcutsq;
+            const double sw = d * d * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * denom_inv;
+            const double dsw = 12.0 * (rsq - ronsq) * d * denom_inv;
+            fdr = sw * fdr - dsw * eng;
+            eng = eng * sw;
+            }
+        }
+    s.fx += dx * fdr;
+    s.fy += dy * fdr;
+    s.fz += dz * fdr;
+    s.pe += eng;
+    if (VIRIAL)
+        {
+        const double f2 = 0.5 * fdr;
+        s.vxx += dx * dx * f2;
+        s.vxy += dx * dy * f2;
+        s.vxz += dx * dz * f2;
+        s.vyy += dy * dy * f2;
+        s.vyz += dy * dz * f2;
+        s.vzz += dz * dz * f2;
+        }
+    }
+
+// fold the TPP lanes of a particle and store force (w = half the pair energy) and virial
+template<bool VIRIAL, int TPP>
+__device__ __forceinline__ void pf_finish(pf_accum& s, const hmd_pair_args_t& a, unsigned int idx, bool writer)
+    {
+    const double fx = pf_reduce<TPP>(s.fx), fy = pf_reduce<TPP>(s.fy), fz = pf_reduce<TPP>(s.fz);
+    const double pe = 0.5 * pf_reduce<TPP>(s.pe);
+    if (writer)
+        hmd_st4(a.d_force + idx, fx, fy, fz, pe);
+    if (VIRIAL)
+        {
+        const double vxx = pf_reduce<TPP>(s.vxx), vxy = pf_reduce<TPP>(s.vxy), vxz = pf_reduce<TPP>(s.vxz);
+        const double vyy = pf_reduce<TPP>(s.vyy), vyz = pf_reduce<TPP>(s.vyz), vzz = pf_reduce<TPP>(s.vzz);
+        if (writer)
+            {
+            a.d_virial[0 * a.virial_pitch + idx] = vxx;
+            a.d_virial[1 * a.virial_pitch + idx] = vxy;
+            a.d_virial[2 * a.virial_pitch + idx] = vxz;
+            a.d_virial[3 * a.virial_pitch + idx] = vyy;
+            a.d_virial[4 * a.virial_pitch + idx] = vyz;
+            a.d_virial[5 * a.virial_pitch + idx] = vzz;
+            }
+        }
+    }
+
 constexpr int PF_VEC = 4; // neighbors handled per lane per loop trip (one 16-byte index load)
 
 template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE, bool ORTHO>
@@ -114,8 +205,7 @@ __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a,
     const unsigned int sub = threadIdx.x % TPP;
     const bool active = idx < a.N;
 
-    double fx = 0, fy = 0, fz = 0, pe = 0;
-    double vxx = 0, vxy = 0, vxz = 0, vyy = 0, vyz = 0, vzz = 0;
+    pf_accum acc;
 
     if (active)
         {
@@ -131,48 +221,34 @@ __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a,
         // neighbor-list build produces) are read four indices at a time
         const bool vec_ok = ((head & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.d_nlist) & 15) == 0) && (a.size_neigh_list >= head + ((nn + 3) & ~3u));
 
-        auto load4 = [&](unsigned int k) -> uint4
+        // Lane `sub` of the particle's TPP lanes takes entries kb + m*TPP + sub, m = 0..3, of each
+        // 4*TPP-entry slab: neighboring lanes gather neighboring list entries, which in a cell-sorted
+        // system are mostly neighboring particles -- their 32-byte positions share cache lines.
+        auto load_slab = [&](unsigned int kb, unsigned int (&v)[PF_VEC])
         {
-            uint4 v = make_uint4(idx, idx, idx, idx);
-            if (k < nn)
-                {
-                if (vec_ok)
-                    v = *reinterpret_cast<const uint4*>(row + k);
-                else
-                    {
-                    v.x = row[k];
-                    if (k + 1 < nn)
-                        v.y = row[k + 1];
-                    if (k + 2 < nn)
-                        v.z = row[k + 2];
-                    if (k + 3 < nn)
-                        v.w = row[k + 3];
-                    }
-                }
-            return v;
-        };
-
-        uint4 cur = load4(sub * PF_VEC);
-        for (unsigned int k = sub * PF_VEC; k < nn; k += TPP * PF_VEC)
-            {
-            // index slab of the next trip: in flight while this trip's positions are gathered
-            const uint4 nxt = load4(k + TPP * PF_VEC);
-            unsigned int j[PF_VEC] = {cur.x, cur.y, cur.z, cur.w};
-            double4 pj[PF_VEC];
 #pragma unroll
             for (int m = 0; m < PF_VEC; m++)
                 {
-                // entries past the end of the row may hold anything: point them at the particle itself
-                j[m] = (k + m < nn) ? j[m] : idx;
-                pj[m] = hmd_ld4(a.d_pos + j[m]);
+                const unsigned int e = kb + m * TPP + sub;
+                v[m] = (e < nn) ? row[e] : idx;
                 }
+        };
+        (void)vec_ok;
+        unsigned int cur[PF_VEC], nxt[PF_VEC];
+        load_slab(0, cur);
+        for (unsigned int kb = 0; kb < nn; kb += TPP * PF_VEC)
+            {
+            // index slab of the next trip: in flight while this trip's positions are gathered
+            load_slab(kb + TPP * PF_VEC, nxt);
+            double4 pj[PF_VEC];
+#pragma unroll
+            for (int m = 0; m < PF_VEC; m++)
+                pj[m] = hmd_ld4(a.d_pos + cur[m]);
 #pragma unroll
             for (int m = 0; m < PF_VEC; m++)
                 {
                 double dx = pi.x - pj[m].x, dy = pi.y - pj[m].y, dz = pi.z - pj[m].z;
                 pf_min_image<ORTHO>(box, dx, dy, dz);
-                const double rsq = dx * dx + dy * dy + dz * dz;
-
                 double rcutsq, ronsq = 0.0;
                 const param_t* prm;
                 if (SINGLE_TYPE)
@@ -190,86 +266,19 @@ __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a,
                     prm = s_params + tp;
                     }
                 // the padding entries (j == idx) sit at rsq = 0; disable them through the cutoff
-                if (k + m >= nn)
+                if (kb + m * TPP + sub >= nn)
                     rcutsq = -1.0;
-
-                bool energy_shift = false;
-                if (SHIFT == 1)
-                    energy_shift = true;
-                else if (SHIFT == 2)
-                    energy_shift = ronsq > rcutsq;
-
-                double fdr = 0.0, eng = 0.0;
-                Ev ev(rsq, rcutsq, *prm);
+                double qj = 0.0;
                 if (Ev::needsCharge())
-                    ev.setCharge(qi, a.d_charge[j[m]]);
-                const bool evaluated = ev.evalForceAndEnergy(fdr, eng, energy_shift);
-                if (!evaluated)
-                    {
-                    fdr = 0.0;
-                    eng = 0.0;
-                    }
-
-                if (SHIFT == 2)
-                    {
-                    if (evaluated && rsq >= ronsq && rsq < rcutsq)
-                        {
-                        // XPLOR switching, hoomd/md/PotentialPair.h:711-737
-                        const double d3 = (rcutsq - ronsq) * (rcutsq - ronsq) * (rcutsq - ronsq);
-                        const double denom_inv = 1.0 / d3;
-                        const double d = rsq - rcutsq;
-                        const double sw = d * d * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * denom_inv;
-                        const double dsw = 12.0 * (rsq - ronsq) * d * denom_inv;
-                        fdr = sw * fdr - dsw * eng;
-                        eng = eng * sw;
-                        }
-                    }
-
-                fx += dx * fdr;
-                fy += dy * fdr;
-                fz += dz * fdr;
-                pe += eng;
-                if (VIRIAL)
-                    {
-                    const double f2 = 0.5 * fdr;
-                    vxx += dx * dx * f2;
-                    vxy += dx * dy * f2;
-                    vxz += dx * dz * f2;
-                    vyy += dy * dy * f2;
-                    vyz += dy * dz * f2;
-                    vzz += dz * dz * f2;
-                    }
+                    qj = a.d_charge[cur[m]];
+                pf_pair<Ev, SHIFT, VIRIAL>(acc, dx, dy, dz, rcutsq, ronsq, *prm, qi, qj);
                 }
-            cur = nxt;
-            }
-        pe *= 0.5;
-        }
-
-    fx = pf_reduce<TPP>(fx);
-    fy = pf_reduce<TPP>(fy);
-    fz = pf_reduce<TPP>(fz);
-    pe = pf_reduce<TPP>(pe);
-    if (active && sub == 0)
-        hmd_st4(a.d_force + idx, fx, fy, fz, pe);
-
-    if (VIRIAL)
-        {
-        vxx = pf_reduce<TPP>(vxx);
-        vxy = pf_reduce<TPP>(vxy);
-        vxz = pf_reduce<TPP>(vxz);
-        vyy = pf_reduce<TPP>(vyy);
-        vyz = pf_reduce<TPP>(vyz);
-        vzz = pf_reduce<TPP>(vzz);
-        if (active && sub == 0)
-            {
-            a.d_virial[0 * a.virial_pitch + idx] = vxx;
-            a.d_virial[1 * a.virial_pitch + idx] = vxy;
-            a.d_virial[2 * a.virial_pitch + idx] = vxz;
-            a.d_virial[3 * a.virial_pitch + idx] = vyy;
-            a.d_virial[4 * a.virial_pitch + idx] = vyz;
-            a.d_virial[5 * a.virial_pitch + idx] = vzz;
+#pragma unroll
+            for (int m = 0; m < PF_VEC; m++)
+                cur[m] = nxt[m];
             }
         }
+    pf_finish<VIRIAL, TPP>(acc, a, idx, active && sub == 0);
     }
 
 template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP>

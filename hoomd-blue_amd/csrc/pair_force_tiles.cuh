@@ -1,0 +1,361 @@
+// pair_force_tiles.cuh -- pair forces from LDS tiles.
+//
+// Same per-pair arithmetic and outputs as pair_force.cuh (hoomd/md/PotentialPairGPU.cuh:140-404); the
+// neighbor rows hold 16-bit candidate numbers of the workgroup's region (tile.cuh), so a neighbor's
+// coordinates are three LDS reads and the periodic image is already applied.  TPP lanes share a
+// home particle; each lane takes four consecutive row entries (one 8-byte load) per trip.
+#ifndef HMD_PAIR_FORCE_TILES_CUH
+#define HMD_PAIR_FORCE_TILES_CUH
+
+#include "pair_force.cuh"
+#include "tile.cuh"
+
+namespace hmd
+    {
+// per home particle, kept in LDS so that no wave waits on a chain of dependent global loads
+struct pft_home_t
+    {
+    unsigned int idx, nn;
+    unsigned int row; // offset of the particle's row in d_tile_nlist, in units of four entries
+    unsigned int lh;  // candidate number of the particle itself
+    };
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE>
+__global__ void __launch_bounds__(TL_THREADS)
+    pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
+    {
+    typedef typename Ev::param_type param_t;
+    __shared__ tile_tables T;
+    __shared__ unsigned int s_next;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const unsigned int cap = g.capacity;
+    // candidate c sits at txyz[3c .. 3c+2]; slot `total` is a dummy far away that padding entries point to
+    double* txyz = reinterpret_cast<double*>(s_dyn);
+    pft_home_t* s_home = reinterpret_cast<pft_home_t*>(txyz + 3 * ((size_t)cap + 1));
+    const unsigned int np = a.ntypes * a.ntypes;
+    double* s_rcutsq = reinterpret_cast<double*>(s_home + 8 * g.cli.w);
+    double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
+    param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
+    unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
+
+    int cx0, cy0, cz0;
+    tile_setup(g, a.box, T, cx0, cy0, cz0);
+    param_t p0;
+    double rcutsq0 = 0.0, ronsq0 = 0.0;
+    if (SINGLE_TYPE)
+        {
+        p0 = d_params[0];
+        rcutsq0 = a.d_rcutsq[0];
+        if (SHIFT == 2)
+            ronsq0 = a.d_ronsq[0];
+        }
+    else
+        for (unsigned int t = threadIdx.x; t < np; t += TL_THREADS)
+            {
+            s_params[t] = d_params[t];
+            s_rcutsq[t] = a.d_rcutsq[t];
+            s_ronsq[t] = (SHIFT == 2) ? a.d_ronsq[t] : 0.0;
+            }
+    if (threadIdx.x == 0)
+        s_next = TL_THREADS / TPP;
+    __syncthreads();
+    const unsigned int total = T.off[TL_RC];
+    if (total > cap || total == 0)
+        return;
+
+    // ---- home particles: members of the (up to 8) home cells, numbered consecutively ----
+    unsigned int hbeg[8], hcum[9];
+    hcum[0] = 0;
+#pragma unroll
+    for (int hc = 0; hc < 8; hc++)
+        {
+        const int hx = hc & 1, hy = (hc >> 1) & 1, hz = hc >> 2;
+        const unsigned int rc = ((hz + 1) * 4 + (hy + 1)) * 4 + (hx + 1);
+        const bool home = tile_is_home(g, cx0, cy0, cz0, hx, hy, hz);
+        hbeg[hc] = T.off[rc];
+        hcum[hc + 1] = hcum[hc] + (home ? T.off[rc + 1] - T.off[rc] : 0u);
+        }
+    const unsigned int H = hcum[8];
+    auto home_local = [&](unsigned int h, unsigned int& rc_home) -> unsigned int
+    {
+        unsigned int lh = 0;
+        rc_home = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            if (h >= hcum[c] && h < hcum[c + 1])
+                {
+                lh = hbeg[c] + (h - hcum[c]);
+                rc_home = ((((c >> 2) + 1) * 4 + (((c >> 1) & 1) + 1)) * 4 + ((c & 1) + 1));
+                }
+        return lh;
+    };
+    // ---- stage the region (one wave per region cell, eight cells in flight) and the home table.
+    // Loads are issued in two dependent rounds only: member indices, then positions / row info. ----
+    const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    unsigned int my_h = threadIdx.x, my_idx = 0, my_lh = 0;
+    if (my_h < H)
+        {
+        unsigned int rc_home;
+        my_lh = home_local(my_h, rc_home);
+        my_idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (my_lh - T.off[rc_home])];
+        }
+#pragma unroll
+    for (int round = 0; round < 2; round++)
+        {
+        const unsigned int rc0 = wave * 16 + round * 8;
+        unsigned int idx[8];
+        bool on[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            {
+            const unsigned int rc = rc0 + q;
+            on[q] = lane < T.off[rc + 1] - T.off[rc];
+            idx[q] = on[q] ? g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + lane] : 0u;
+            }
+        double4 p[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            p[q] = hmd_ld4(a.d_pos + idx[q]);
+        if (round == 0 && my_h < H)
+            {
+            pft_home_t e;
+            e.idx = my_idx;
+            e.nn = 0;
+            e.row = 0;
+            e.lh = my_lh;
+            if (my_idx < a.N)
+                {
+                e.nn = a.d_n_neigh[my_idx];
+                e.row = (unsigned int)(a.d_head_list[my_idx] / 4);
+                }
+            s_home[my_h] = e;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            {
+            const unsigned int rc = rc0 + q;
+            if (on[q])
+                {
+                const unsigned int v = T.off[rc] + lane;
+                double x = p[q].x, y = p[q].y, z = p[q].z;
+                tile_place(a.box, T, rc, x, y, z);
+                txyz[3 * v + 0] = x;
+                txyz[3 * v + 1] = y;
+                txyz[3 * v + 2] = z;
+                if (!SINGLE_TYPE)
+                    ttype[v] = (unsigned char)hmd_double_as_uint(p[q].w);
+                }
+            }
+        }
+    // the uncommon leftovers: cells with more than 64 members, blocks with more than 256 home particles
+    for (unsigned int rc = wave * 16; rc < wave * 16 + 16; rc++)
+        {
+        const unsigned int size = T.off[rc + 1] - T.off[rc];
+        for (unsigned int k = lane + 64; k < size; k += 64)
+            {
+            const unsigned int j = g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + k];
+            const double4 pp = hmd_ld4(a.d_pos + j);
+            const unsigned int v = T.off[rc] + k;
+            double x = pp.x, y = pp.y, z = pp.z;
+            tile_place(a.box, T, rc, x, y, z);
+            txyz[3 * v + 0] = x;
+            txyz[3 * v + 1] = y;
+            txyz[3 * v + 2] = z;
+            if (!SINGLE_TYPE)
+                ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
+            }
+        }
+    for (unsigned int h = threadIdx.x + TL_THREADS; h < H; h += TL_THREADS)
+        {
+        unsigned int rc_home;
+        const unsigned int lh = home_local(h, rc_home);
+        pft_home_t e;
+        e.idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
+        e.nn = 0;
+        e.row = 0;
+        e.lh = lh;
+        if (e.idx < a.N)
+            {
+            e.nn = a.d_n_neigh[e.idx];
+            e.row = (unsigned int)(a.d_head_list[e.idx] / 4);
+            }
+        s_home[h] = e;
+        }
+    if (threadIdx.x == 0)
+        {
+        txyz[3 * total + 0] = 1e30;
+        txyz[3 * total + 1] = 1e30;
+        txyz[3 * total + 2] = 1e30;
+        if (!SINGLE_TYPE)
+            ttype[total] = 0;
+        }
+    __syncthreads();
+
+    // ---- forces: groups of TPP lanes take home particles from a shared counter.  A row is fetched
+    // whole (PFT_CH chunks of four entries per lane) one home particle ahead of its use: rows stream
+    // from HBM exactly once, so what bounds this phase is the number of bytes in flight. ----
+    constexpr int PFT_CH = 4;
+    const unsigned int sub = threadIdx.x % TPP;
+    const unsigned int leader = (lane / TPP) * TPP;
+    const unsigned char* rows = reinterpret_cast<const unsigned char*>(d_tile_nlist);
+    const pft_home_t none = {0u, 0u, 0u, 0u};
+    // Rows are padded to a multiple of four entries with 0xffff (-> the dummy slot).  Chunks past the
+    // end of a row read the following rows or the 512-byte slack after the last one; never used.
+    auto fetch = [&](const pft_home_t& e, uint2 (&c)[PFT_CH])
+    {
+        const uint2* row = reinterpret_cast<const uint2*>(rows) + e.row;
+#pragma unroll
+        for (int q = 0; q < PFT_CH; q++)
+            c[q] = row[sub + TPP * q];
+    };
+    unsigned int h = threadIdx.x / TPP;
+    pft_home_t e = (h < H) ? s_home[h] : none;
+    uint2 cur[PFT_CH];
+    fetch(e, cur);
+    while (h < H)
+        {
+        unsigned int nh = 0;
+        if (sub == 0)
+            nh = atomicAdd(&s_next, 1u);
+        const unsigned int h_next = __shfl(nh, leader, 64);
+        const pft_home_t e_next = (h_next < H) ? s_home[h_next] : none;
+        uint2 nxt[PFT_CH];
+        fetch(e_next, nxt);
+
+        const unsigned int lh = e.lh;
+        pf_accum acc;
+        const unsigned int nn = e.nn;
+        const double xi = txyz[3 * lh], yi = txyz[3 * lh + 1], zi = txyz[3 * lh + 2];
+        const unsigned int ti = SINGLE_TYPE ? 0u : (unsigned int)ttype[lh];
+        auto chunk = [&](uint2 w)
+        {
+            unsigned int j[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+            double xj[4], yj[4], zj[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                {
+                j[m] = min(j[m], total);
+                xj[m] = txyz[3 * j[m]];
+                yj[m] = txyz[3 * j[m] + 1];
+                zj[m] = txyz[3 * j[m] + 2];
+                }
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                {
+                double rcutsq, ronsq = 0.0;
+                const param_t* prm;
+                if (SINGLE_TYPE)
+                    {
+                    rcutsq = rcutsq0;
+                    ronsq = ronsq0;
+                    prm = &p0;
+                    }
+                else
+                    {
+                    const unsigned int tp = (unsigned int)ttype[j[m]] * a.ntypes + ti;
+                    rcutsq = s_rcutsq[tp];
+                    if (SHIFT == 2)
+                        ronsq = s_ronsq[tp];
+                    prm = s_params + tp;
+                    }
+                pf_pair<Ev, SHIFT, VIRIAL>(acc, xi - xj[m], yi - yj[m], zi - zj[m], rcutsq, ronsq, *prm, 0.0, 0.0);
+                }
+        };
+#pragma unroll
+        for (int q = 0; q < PFT_CH; q++)
+            if (4 * (sub + TPP * q) < nn)
+                chunk(cur[q]);
+        // rows longer than PFT_CH * 4 * TPP entries
+        for (unsigned int k = 4 * (sub + TPP * PFT_CH); k < nn; k += 4 * TPP)
+            chunk((reinterpret_cast<const uint2*>(rows) + e.row)[k / 4]);
+
+        pf_finish<VIRIAL, TPP>(acc, a, e.idx, e.idx < a.N && sub == 0);
+        h = h_next;
+        e = e_next;
+#pragma unroll
+        for (int q = 0; q < PFT_CH; q++)
+            cur[q] = nxt[q];
+        }
+    }
+
+template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned int ntypes, unsigned int cell_Nmax)
+    {
+    size_t b = ((size_t)cap + 1) * 24 + (size_t)8 * cell_Nmax * sizeof(pft_home_t);
+    if (ntypes > 1)
+        b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + cap + 1;
+    return (b + 15) / 16 * 16;
+    }
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL>
+int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsigned short* d_tile_nlist,
+                const typename Ev::param_type* d_params, unsigned int tpp, hipStream_t s)
+    {
+    const size_t lds = pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w);
+    const dim3 grid(tile_num_blocks(g.ci)), block(TL_THREADS);
+#define HMD_PFT_LAUNCH(TPPV)                                                                                               \
+    if (a.ntypes == 1)                                                                                                     \
+        {                                                                                                                  \
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, true>, lds);                                   \
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params);  \
+        }                                                                                                                  \
+    else                                                                                                                   \
+        {                                                                                                                  \
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, false>, lds);                                  \
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params); \
+        }
+    switch (tpp)
+        {
+    case 4:
+        HMD_PFT_LAUNCH(4) break;
+    case 16:
+        HMD_PFT_LAUNCH(16) break;
+    default:
+        HMD_PFT_LAUNCH(8) break;
+        }
+#undef HMD_PFT_LAUNCH
+    return hmd_launch_status();
+    }
+
+template<class Ev>
+int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom, const unsigned short* d_tile_nlist,
+                             const typename Ev::param_type* d_params, void* stream)
+    {
+    HMD_REQUIRE(args && geom && d_tile_nlist && d_params, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): args, geom, d_tile_nlist and d_params are required");
+    const hmd_pair_args_t& a = *args;
+    const hmd_tile_geom_t& g = *geom;
+    HMD_REQUIRE(a.d_force && a.d_pos && a.d_n_neigh && a.d_head_list && a.d_rcutsq, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): force, pos, n_neigh, head_list and rcutsq are required");
+    HMD_REQUIRE(g.d_cell_size && g.d_cell_idx, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): the cell arrays are required");
+    HMD_REQUIRE((reinterpret_cast<uintptr_t>(d_tile_nlist) & 7) == 0, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): d_tile_nlist must be 8-byte aligned");
+    HMD_REQUIRE(a.size_neigh_list / 4 <= 0xffffffffull, HMD_ERR_TOO_LARGE, "pair forces (tiles): more than 2^34 row entries");
+    HMD_REQUIRE(a.shift_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): shift_mode must be 0, 1 or 2");
+    HMD_REQUIRE(a.shift_mode != 2 || a.d_ronsq, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): xplor needs d_ronsq");
+    HMD_REQUIRE(!a.compute_virial || a.d_virial, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): compute_virial needs d_virial");
+    HMD_REQUIRE(!Ev::needsCharge(), HMD_ERR_UNSUPPORTED, "pair forces (tiles): evaluators that need charges use the row-based entry point");
+    unsigned int cap = 0;
+    const int rc = hmd_nlist_tiles_supported(&g.ci, &a.box, g.cli.w, a.ntypes, &cap);
+    if (rc != HMD_OK)
+        return rc;
+    HMD_REQUIRE(g.capacity >= 1 && g.capacity <= cap, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): geom.capacity must be in [1, 64 * cli.w]");
+    HMD_REQUIRE(pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w) <= TL_MAX_LDS, HMD_ERR_TOO_LARGE, "pair forces (tiles): tile exceeds the LDS budget");
+    const unsigned int tpp = a.threads_per_particle ? a.threads_per_particle : 8;
+    HMD_REQUIRE(tpp == 4 || tpp == 8 || tpp == 16, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): threads_per_particle must be 4, 8 or 16");
+    if (a.N == 0)
+        return HMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vir = a.compute_virial != 0;
+    switch (a.shift_mode)
+        {
+    case 0:
+        return vir ? pft_launch2<Ev, 0, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 0, false>(a, g, d_tile_nlist, d_params, tpp, s);
+    case 1:
+        return vir ? pft_launch2<Ev, 1, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 1, false>(a, g, d_tile_nlist, d_params, tpp, s);
+    default:
+        return vir ? pft_launch2<Ev, 2, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 2, false>(a, g, d_tile_nlist, d_params, tpp, s);
+        }
+    }
+    } // namespace hmd
+
+#endif

@@ -151,6 +151,22 @@ class PackPosArgs(C.Structure):
                 ("n_send", u32)]
 
 
+class TileGeom(C.Structure):
+    _fields_ = [("d_cell_size", vp), ("d_cell_idx", vp), ("ci", Index3D), ("cli", Index2D), ("capacity", u32)]
+
+
+class NlistTilesArgs(C.Structure):
+    _fields_ = [("geom", TileGeom), ("d_cell_xyzf", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp), ("cadji", Index2D),
+                ("d_tile_nlist", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp),
+                ("d_Nmax", vp), ("d_head_list", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
+                ("ntypes", u32), ("d_tile_overflow", vp)]
+
+
+class TilesToRowsArgs(C.Structure):
+    _fields_ = [("geom", TileGeom), ("d_tile_nlist", vp), ("d_n_neigh", vp), ("d_head_list", vp), ("d_nlist", vp), ("N", u32),
+                ("box", Box)]
+
+
 # every symbol the header declares, with its signature
 _SIGNATURES = {
     "hmd_box_init": (None, [C.POINTER(Box), f64, f64, f64, f64, f64, f64]),
@@ -179,6 +195,11 @@ _SIGNATURES = {
     "hmd_build_rtag": (C.c_int, [vp, vp, u32, vp]),
     "hmd_make_ghost_exchange_plan": (C.c_int, [C.POINTER(GhostPlanArgs), vp]),
     "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
+    "hmd_nlist_tiles_supported": (C.c_int, [C.POINTER(Index3D), C.POINTER(Box), u32, u32, C.POINTER(u32)]),
+    "hmd_compute_nlist_tiles": (C.c_int, [C.POINTER(NlistTilesArgs), vp]),
+    "hmd_nlist_tiles_to_rows": (C.c_int, [C.POINTER(TilesToRowsArgs), vp]),
+    "hmd_compute_pair_forces_lj_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
+    "hmd_compute_pair_forces_example_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -181,6 +181,86 @@ def pair_forces(evaluator, pos, N, box, n_neigh, nlist, head, params, rcutsq, ro
     return force, virial
 
 
+def tile_geom(cl, box, ntypes=1, capacity=None):
+    """Tile geometry of a cell list built with want_idx=True; raises KernelError when unsupported."""
+    g = _abi.TileGeom()
+    g.d_cell_size, g.d_cell_idx = ptr(cl["cell_size"]), ptr(cl["idx"])
+    g.ci = Index3D(*cl["dim"])
+    g.cli = Index2D(cl["Nmax"], cl["cell_size"].numel())
+    cap = C.c_uint(0)
+    check(_abi.lib.hmd_nlist_tiles_supported(C.byref(g.ci), C.byref(box), cl["Nmax"], ntypes, C.byref(cap)), "hmd_nlist_tiles_supported")
+    g.capacity = cap.value if capacity is None else capacity
+    return g
+
+
+def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
+    """Tile build with the head-list / overflow protocol of nlist_binned."""
+    dev = pos.device
+    r_cut_t = torch.as_tensor(np.asarray(r_cut, dtype=np.float64), device=dev).contiguous()
+    nt = r_cut_t.shape[0]
+    geom = tile_geom(cl, box, nt, capacity)
+    Nmax_t = torch.full((nt,), 4, dtype=torch.int32, device=dev)
+    last_pos = torch.zeros((max(N, 1), 4), dtype=torch.float64, device=dev)
+    overflow = torch.zeros(2, dtype=torch.int32, device=dev)
+    n_builds = 0
+    while True:
+        head, total = build_head_list(pos, N, Nmax_t)
+        tiles = torch.zeros(max(total, 4) + 256, dtype=torch.int16, device=dev)  # 512 bytes of slack for the force kernel's prefetch
+        n_neigh = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+        cond = torch.zeros(nt, dtype=torch.int32, device=dev)
+        a = _abi.NlistTilesArgs()
+        a.geom = geom
+        a.d_cell_xyzf, a.d_cell_type_body, a.d_cell_adj = ptr(cl["xyzf"]), ptr(cl["type_body"]), ptr(adj)
+        a.cadji = Index2D(adj.shape[1], cl["cell_size"].numel())
+        a.d_tile_nlist, a.d_n_neigh, a.d_last_updated_pos, a.d_conditions = ptr(tiles), ptr(n_neigh), ptr(last_pos), ptr(cond)
+        a.d_Nmax, a.d_head_list, a.d_pos, a.N, a.box = ptr(Nmax_t), ptr(head), ptr(pos), N, box
+        a.d_r_cut, a.r_buff, a.ntypes, a.d_tile_overflow = ptr(r_cut_t), float(r_buff), nt, ptr(overflow)
+        check(_abi.lib.hmd_compute_nlist_tiles(C.byref(a), _stream(pos)), "hmd_compute_nlist_tiles")
+        n_builds += 1
+        if int(overflow[0].item()):
+            raise _abi.KernelError("tile capacity exceeded")
+        c = cond.cpu().numpy().astype(np.int64)
+        nm = Nmax_t.cpu().numpy().astype(np.int64)
+        over = c > nm
+        if over.any():
+            nm[over] = np.where(c[over] > 4, (c[over] + 3) & ~3, 4)
+            Nmax_t = torch.as_tensor(nm.astype(np.int32), device=dev)
+            continue
+        # geom points into the cell list's tensors: keep them alive with the result
+        return dict(tiles=tiles, n_neigh=n_neigh, head=head, last_pos=last_pos, Nmax=Nmax_t, n_builds=n_builds, geom=geom, args=a,
+                    cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow)
+
+
+def tiles_to_rows(tl, N, box):
+    dev = tl["tiles"].device
+    nlist = torch.full((tl["tiles"].numel(),), -1, dtype=torch.int32, device=dev)
+    a = _abi.TilesToRowsArgs()
+    a.geom = tl["geom"]
+    a.d_tile_nlist, a.d_n_neigh, a.d_head_list, a.d_nlist, a.N, a.box = ptr(tl["tiles"]), ptr(tl["n_neigh"]), ptr(tl["head"]), ptr(nlist), N, box
+    check(_abi.lib.hmd_nlist_tiles_to_rows(C.byref(a), _stream(nlist)), "hmd_nlist_tiles_to_rows")
+    return nlist
+
+
+def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, shift_mode=0, compute_virial=True, tpp=0, n_total=None):
+    dev = pos.device
+    n_total = pos.shape[0] if n_total is None else n_total
+    prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
+    rc = torch.as_tensor(np.asarray(rcutsq, dtype=np.float64), device=dev).contiguous()
+    nt = rc.shape[0]
+    ro = torch.as_tensor(np.asarray(ronsq if ronsq is not None else np.zeros((nt, nt)), dtype=np.float64), device=dev).contiguous()
+    force = torch.full((n_total, 4), float("nan"), dtype=torch.float64, device=dev)
+    virial = torch.full((6, n_total), float("nan"), dtype=torch.float64, device=dev) if compute_virial else None
+    a = _abi.PairArgs()
+    a.d_force, a.d_virial, a.virial_pitch = ptr(force), ptr(virial), n_total
+    a.N, a.n_max, a.d_pos, a.box = N, n_total, ptr(pos), box
+    a.d_n_neigh, a.d_nlist, a.d_head_list = ptr(tl["n_neigh"]), None, ptr(tl["head"])
+    a.d_rcutsq, a.d_ronsq, a.size_neigh_list, a.ntypes = ptr(rc), ptr(ro), tl["tiles"].numel(), nt
+    a.shift_mode, a.compute_virial, a.threads_per_particle = shift_mode, int(compute_virial), tpp
+    fn = {"lj": _abi.lib.hmd_compute_pair_forces_lj_tiles, "example": _abi.lib.hmd_compute_pair_forces_example_tiles}[evaluator]
+    check(fn(C.byref(a), C.byref(tl["geom"]), ptr(tl["tiles"]), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_%s_tiles" % evaluator)
+    return force, virial
+
+
 def sum_net_force(forces, virials=None, net_force=None, net_virial=None, clear=True):
     dev = forces[0].device
     n = forces[0].shape[0]

@@ -77,7 +77,7 @@ void CellListGPU::initializeMemory()
     for (int d = 0; d < 3; d++)
         u[d] = m_dim[d] > m_radius * 2 + 1 ? m_radius * 2 + 1 : m_dim[d];
     m_n_adj = (m_sysdef->getNDimensions() == 2) ? u[0] * u[1] : u[0] * u[1] * u[2];
-    m_cell_adj.resize((size_t)m_n_adj * ncells, false);
+    m_cell_adj.resize(m_compute_adj ? (size_t)m_n_adj * ncells : 0, false);
     m_xyzf.resize((size_t)m_Nmax * ncells, false);
     if (m_compute_type_body)
         m_type_body.resize((size_t)m_Nmax * ncells, false);
@@ -87,7 +87,8 @@ void CellListGPU::initializeMemory()
         m_idx.resize((size_t)m_Nmax * ncells, false);
     else
         m_idx.resize(0, false);
-    initializeCellAdj();
+    if (m_compute_adj)
+        initializeCellAdj();
     }
 
 // hoomd/CellList.cc:346-402 : built on the host once per geometry change, then uploaded

@@ -185,19 +185,28 @@ template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     a.d_pos = m_pdata->pos();
     a.d_charge = m_pdata->charge();
     a.box = m_pdata->getBox().b;
+    const bool tiles = m_nlist->tilesActive();
     a.d_n_neigh = m_nlist->getNNeighArray().get();
-    a.d_nlist = m_nlist->getNListArray().get();
+    a.d_nlist = tiles ? nullptr : m_nlist->getNListArray().get();
     a.d_head_list = m_nlist->getHeadList().get();
     a.d_rcutsq = m_d_rcutsq.get();
     a.d_ronsq = m_d_ronsq.get();
-    a.size_neigh_list = m_nlist->getNListArray().size();
+    a.size_neigh_list = tiles ? m_nlist->getTileNlist().size() : m_nlist->getNListArray().size();
     a.ntypes = m_ntypes;
     a.shift_mode = (unsigned int)m_shift_mode;
     a.compute_virial = m_pdata->getFlag(pressure_tensor) ? 1u : 0u;
     a.threads_per_particle = m_tpp;
+    if (tiles && m_tpp != 4 && m_tpp != 8 && m_tpp != 16)
+        a.threads_per_particle = 0; // the tile kernel is built for 4, 8 and 16 lanes per particle
         {
         ScopedKernelTimer t("pair_force");
-        abiCheck(Ev::launch(&a, m_d_params.get(), nullptr), "gpu_compute_pair_forces");
+        if (tiles)
+            {
+            const hmd_tile_geom_t g = m_nlist->getTileGeom();
+            abiCheck(Ev::launchTiles(&a, &g, m_nlist->getTileNlist().get(), m_d_params.get(), nullptr), "gpu_compute_pair_forces (tiles)");
+            }
+        else
+            abiCheck(Ev::launch(&a, m_d_params.get(), nullptr), "gpu_compute_pair_forces");
         }
     computeTailCorrection();
     }

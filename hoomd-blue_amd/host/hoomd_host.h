@@ -567,13 +567,22 @@ class CellListGPU : public Compute
 
     void setNominalWidth(Scalar w)
         {
+        if (w != m_nominal_width)
+            m_params_changed = true;
         m_nominal_width = w;
-        m_params_changed = true;
         }
     void setRadius(unsigned int r)
         {
+        if (r != m_radius)
+            m_params_changed = true;
         m_radius = r;
-        m_params_changed = true;
+        }
+    //! consumers that never walk neighboring cells (the particle sorter) skip the adjacency table
+    void setComputeAdj(bool b)
+        {
+        if (b != m_compute_adj)
+            m_params_changed = true;
+        m_compute_adj = b;
         }
     void setComputeTypeBody(bool b)
         {
@@ -671,7 +680,7 @@ class CellListGPU : public Compute
     unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0;
     std::array<unsigned int, 3> m_dim {{0, 0, 0}};
     Scalar3 m_ghost_width {0, 0, 0};
-    bool m_params_changed = true, m_particles_sorted = false, m_box_changed = false;
+    bool m_params_changed = true, m_particles_sorted = false, m_box_changed = false, m_compute_adj = true;
     bool m_compute_type_body = false, m_compute_idx = false, m_flag_charge = false, m_flag_type = false, m_sort = false;
     DeviceArray<unsigned int> m_cell_size, m_cell_adj, m_idx;
     DeviceArray<Scalar4> m_xyzf;
@@ -803,10 +812,32 @@ class NeighborListGPUBinned : public Compute
         {
         return m_n_neigh;
         }
-    const DeviceArray<unsigned int>& getNListArray() const
+    //! rows of particle indices (hoomd/md/NeighborList.h:662-739); expanded from the tile rows on first use
+    const DeviceArray<unsigned int>& getNListArray()
         {
+        ensureRows();
         return m_nlist;
         }
+    //! the last build wrote tile rows (16-bit candidate numbers of 4x4x4-cell regions), consumed by
+    //! the tile pair-force kernel; off when exclusions, a body filter or a small grid rule it out
+    bool tilesActive() const
+        {
+        return m_tiles_active;
+        }
+    void setTilesEnabled(bool b)
+        {
+        m_tiles_enabled = b;
+        forceUpdate();
+        }
+    bool getTilesEnabled() const
+        {
+        return m_tiles_enabled;
+        }
+    const DeviceArray<unsigned short>& getTileNlist() const
+        {
+        return m_tile_nlist;
+        }
+    hmd_tile_geom_t getTileGeom() const;
     const DeviceArray<size_t>& getHeadList() const
         {
         return m_head_list;
@@ -844,6 +875,8 @@ class NeighborListGPUBinned : public Compute
     void updateExListIdx();
     void filterNlist();
     void reallocatePerParticle();
+    void ensureRows();
+    bool tilesUsable(unsigned int& capacity);
 
     std::shared_ptr<CellListGPU> m_cl;
     Scalar m_r_buff;
@@ -872,6 +905,11 @@ class NeighborListGPUBinned : public Compute
     DeviceArray<Scalar> m_d_r_cut, m_d_rcut_max;
     DeviceArray<unsigned char> m_workspace;
     PinnedWords m_h_words;
+
+    // tile rows
+    bool m_tiles_enabled = true, m_tiles_active = false, m_rows_valid = true, m_tiles_overflowed = false;
+    unsigned int m_tile_capacity = 0;
+    DeviceArray<unsigned short> m_tile_nlist;
 
     // exclusions
     bool m_exclusions_set = false, m_ex_dirty = false;
@@ -946,6 +984,10 @@ struct EvaluatorLJHost
         {
         return hmd_compute_pair_forces_lj(a, p, s);
         }
+    static int launchTiles(const hmd_pair_args_t* a, const hmd_tile_geom_t* g, const unsigned short* t, const param_type* p, void* s)
+        {
+        return hmd_compute_pair_forces_lj_tiles(a, g, t, p, s);
+        }
     //! hoomd/md/EvaluatorPairLJ.h:213-248
     static Scalar energyLRC(Scalar rcutsq, const param_type& p);
     static Scalar pressureLRC(Scalar rcutsq, const param_type& p);
@@ -961,6 +1003,10 @@ struct EvaluatorExampleHost
     static int launch(const hmd_pair_args_t* a, const param_type* p, void* s)
         {
         return hmd_compute_pair_forces_example(a, p, s);
+        }
+    static int launchTiles(const hmd_pair_args_t* a, const hmd_tile_geom_t* g, const unsigned short* t, const param_type* p, void* s)
+        {
+        return hmd_compute_pair_forces_example_tiles(a, g, t, p, s);
         }
     static Scalar energyLRC(Scalar, const param_type&)
         {

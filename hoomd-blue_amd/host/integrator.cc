@@ -217,6 +217,7 @@ ParticleSorter::ParticleSorter(std::shared_ptr<SystemDefinition> sysdef, uint64_
     {
     m_cl->setRadius(1);
     m_cl->setFlagIndex();
+    m_cl->setComputeAdj(false);
     }
 
 void ParticleSorter::update(uint64_t timestep)

@@ -285,6 +285,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("check_dist", &NeighborListGPUBinned::getDistCheck, &NeighborListGPUBinned::setDistCheck)
         .def_property("deterministic", &NeighborListGPUBinned::getDeterministic, &NeighborListGPUBinned::setDeterministic)
         .def_property_readonly("num_builds", &NeighborListGPUBinned::getNumUpdates)
+        .def_property("tiles", &NeighborListGPUBinned::getTilesEnabled, &NeighborListGPUBinned::setTilesEnabled)
+        .def_property_readonly("tiles_active", &NeighborListGPUBinned::tilesActive)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)
         .def("setFilterBody", &NeighborListGPUBinned::setFilterBody)

@@ -24,7 +24,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
 
     m_d_Nmax.resize(nt);
     m_d_Nmax.upload(m_Nmax.data(), nt);
-    m_conditions.resize(nt);
+    m_conditions.resize(nt + 2); // [nt] = tile capacity overflow flag, [nt + 1] = largest tile population
     m_d_r_cut.resize((size_t)nt * nt);
     m_d_rcut_max.resize(nt);
     m_flag.resize(1);
@@ -35,6 +35,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
     // hoomd/md/NeighborListGPUBinned.cc:19-45
     m_cl->setRadius(1);
     m_cl->setComputeTypeBody(true);
+    m_cl->setComputeIdx(true); // the tile kernels number candidates through the index array
     m_cl->setFlagIndex();
 
     m_sort_slot = m_pdata->getParticleSortSignal().connect([this]() { forceUpdate(); });
@@ -310,9 +311,17 @@ bool NeighborListGPUBinned::checkConditions()
     {
     const unsigned int nt = m_pdata->getNTypes();
     unsigned int* h = m_h_words.get();
-    hipCheck(hipMemcpyAsync(h, m_conditions.get(), sizeof(unsigned int) * nt, hipMemcpyDeviceToHost, 0), "conditions D2H");
+    hipCheck(hipMemcpyAsync(h, m_conditions.get(), sizeof(unsigned int) * (nt + 2), hipMemcpyDeviceToHost, 0), "conditions D2H");
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
     bool result = false;
+    if (h[nt])
+        {
+        // a 64-cell region outgrew the LDS tile: this build falls back to index rows
+        m_tiles_overflowed = true;
+        result = true;
+        }
+    else if (m_tiles_active && h[nt + 1])
+        m_tile_capacity = h[nt + 1]; // exact: the force kernel sizes its LDS tile by it
     for (unsigned int i = 0; i < nt; i++)
         if (h[i] > m_Nmax[i])
             {
@@ -342,6 +351,40 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
     m_cl->compute(timestep);
 
     ScopedKernelTimer t("nlist_build");
+    unsigned int capacity = 0;
+    if (tilesUsable(capacity))
+        {
+        if (m_tile_nlist.size() < m_nlist.size() + 256)
+            m_tile_nlist.resize(m_nlist.size() + 256, false);
+        hmd_nlist_tiles_args_t a;
+        std::memset(&a, 0, sizeof(a));
+        m_tile_capacity = capacity;
+        a.geom = getTileGeom();
+        a.d_cell_xyzf = m_cl->getXYZFArray().get();
+        a.d_cell_type_body = m_cl->getTypeBodyArray().get();
+        a.d_cell_adj = m_cl->getCellAdjArray().get();
+        a.cadji = m_cl->getCellAdjIndexer();
+        a.d_tile_nlist = m_tile_nlist.get();
+        a.d_n_neigh = m_n_neigh.get();
+        a.d_last_updated_pos = m_last_pos.get();
+        a.d_conditions = m_conditions.get();
+        a.d_Nmax = m_d_Nmax.get();
+        a.d_head_list = m_head_list.get();
+        a.d_pos = m_pdata->pos();
+        a.N = m_pdata->getN();
+        a.box = m_pdata->getBox().b;
+        a.d_r_cut = m_d_r_cut.get();
+        a.r_buff = m_r_buff;
+        a.ntypes = m_pdata->getNTypes();
+        a.d_tile_overflow = m_conditions.get() + a.ntypes;
+        hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
+        abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
+        m_tiles_active = true;
+        m_rows_valid = false;
+        return;
+        }
+    m_tiles_active = false;
+    m_rows_valid = true;
     hmd_nlist_binned_args_t a;
     std::memset(&a, 0, sizeof(a));
     a.d_nlist = m_nlist.get();
@@ -369,6 +412,49 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
     abiCheck(hmd_compute_nlist_binned(&a, nullptr), "hmd_compute_nlist_binned");
     }
 
+hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
+    {
+    hmd_tile_geom_t g;
+    std::memset(&g, 0, sizeof(g));
+    g.d_cell_size = m_cl->getCellSizeArray().get();
+    g.d_cell_idx = m_cl->getIndexArray().get();
+    g.ci = m_cl->getCellIndexer();
+    g.cli = m_cl->getCellListIndexer();
+    g.capacity = m_tile_capacity;
+    return g;
+    }
+
+// can this build write tile rows?  (no row filters, 3D, grid and occupancy within the tile limits)
+bool NeighborListGPUBinned::tilesUsable(unsigned int& capacity)
+    {
+    if (!m_tiles_enabled || m_tiles_overflowed || m_filter_body || m_exclusions_set || m_sysdef->getNDimensions() != 3)
+        return false;
+    const hmd_index3d_t ci = m_cl->getCellIndexer();
+    const hmd_index2d_t cadji = m_cl->getCellAdjIndexer();
+    if (cadji.w != 27)
+        return false;
+    const hmd_box_t box = m_pdata->getBox().b;
+    return hmd_nlist_tiles_supported(&ci, &box, m_cl->getNmax(), m_pdata->getNTypes(), &capacity) == HMD_OK;
+    }
+
+// index rows on demand: consumers other than the tile pair force (pair lists, local access, filters)
+void NeighborListGPUBinned::ensureRows()
+    {
+    if (m_rows_valid)
+        return;
+    hmd_tiles_to_rows_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.geom = getTileGeom();
+    a.d_tile_nlist = m_tile_nlist.get();
+    a.d_n_neigh = m_n_neigh.get();
+    a.d_head_list = m_head_list.get();
+    a.d_nlist = m_nlist.get();
+    a.N = m_pdata->getN();
+    a.box = m_pdata->getBox().b;
+    abiCheck(hmd_nlist_tiles_to_rows(&a, nullptr), "hmd_nlist_tiles_to_rows");
+    m_rows_valid = true;
+    }
+
 // hoomd/md/NeighborList.cc:363-435
 void NeighborListGPUBinned::compute(uint64_t timestep)
     {
@@ -392,6 +478,7 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
     if (needsUpdating(timestep))
         {
         checkBoxSize();
+        m_tiles_overflowed = false;
         bool overflowed = false;
         do
             {
@@ -501,6 +588,7 @@ std::vector<std::pair<unsigned int, unsigned int>> NeighborListGPUBinned::getLoc
     const unsigned int n = m_pdata->getN();
     auto n_neigh = m_n_neigh.toHost(n);
     auto head = m_head_list.toHost(n);
+    ensureRows();
     auto nlist = m_nlist.toHost();
     std::vector<std::pair<unsigned int, unsigned int>> out;
     for (unsigned int i = 0; i < n; i++)

@@ -455,6 +455,81 @@ typedef struct
     } hmd_pack_pos_args_t;
 int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Tile path: the same neighbor list and pair forces, laid out for LDS instead of L1 gathers.
+ * No single reference driver corresponds to these; together they stand in for
+ * gpu_compute_nlist_binned (hoomd/md/NeighborListGPUBinned.cuh:35-62) followed by
+ * gpu_compute_pair_forces<evaluator> (hoomd/md/PotentialPairGPU.cuh:579-583) on the same inputs,
+ * and hmd_nlist_tiles_to_rows reproduces the reference's nlist / n_neigh arrays from them.
+ *
+ * The cell grid is cut into blocks of 2x2x2 cells.  One workgroup stages the block's 4x4x4 region
+ * of cells (periodic images already shifted, so no minimum image per pair) into LDS; candidate k of
+ * the region is numbered by (region cell, slot in the cell list).  A particle's row holds 16-bit
+ * region-local candidate numbers at d_tile_nlist[d_head_list[i] + k], k < d_n_neigh[i], padded with
+ * 0xffff to a multiple of four entries; d_tile_nlist must extend 256 entries (512 bytes) past the
+ * last row (the force kernel prefetches one trip ahead).
+ * The numbering is fixed by d_cell_size / d_cell_idx, which must not change between the build and
+ * its uses.  Requirements (hmd_nlist_tiles_supported): every periodic direction has >= 3 cells and a
+ * region of 64 cells holds at most `capacity` particles.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+    {
+    const unsigned int* d_cell_size; /* particles per cell (hoomd/CellList.h getCellSizeArray) */
+    const unsigned int* d_cell_idx;  /* particle index at cli(slot, cell) (getIndexArray) */
+    hmd_index3d_t ci;
+    hmd_index2d_t cli;
+    unsigned int capacity;           /* candidates per region the LDS tile may hold */
+    } hmd_tile_geom_t;
+
+/* Returns HMD_OK and the LDS capacity to use when the tile path can serve this cell grid, else
+   HMD_ERR_UNSUPPORTED (use the row-based entry points).  cell_Nmax: slots per cell (cli.w). */
+int hmd_nlist_tiles_supported(const hmd_index3d_t* ci, const hmd_box_t* box, unsigned int cell_Nmax, unsigned int ntypes,
+                              unsigned int* capacity_out);
+
+typedef struct
+    {
+    hmd_tile_geom_t geom;
+    const hmd_scalar4* d_cell_xyzf;       /* cell list contents as for hmd_compute_nlist_binned (w = particle index) */
+    const hmd_uint2* d_cell_type_body;    /* may be NULL with a single type */
+    const unsigned int* d_cell_adj;       /* 27-cell stencil */
+    hmd_index2d_t cadji;
+    unsigned short* d_tile_nlist;
+    unsigned int* d_n_neigh;
+    hmd_scalar4* d_last_updated_pos;
+    unsigned int* d_conditions;      /* per type: largest row length seen (atomicMax), as the row-based build */
+    const unsigned int* d_Nmax;
+    const size_t* d_head_list;
+    const hmd_scalar4* d_pos;
+    unsigned int N;                  /* owned particles; cell members with index >= N are ghosts */
+    hmd_box_t box;
+    const double* d_r_cut;           /* ntypes x ntypes */
+    double r_buff;
+    unsigned int ntypes;
+    unsigned int* d_tile_overflow;   /* two words: [0] set to 1 when a region exceeds geom.capacity (rows are then
+                                        invalid); [1] raised (atomicMax) to the largest region population, the
+                                        capacity later calls on these rows need */
+    } hmd_nlist_tiles_args_t;
+int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void* stream);
+
+/* Expand tile rows into particle indices: d_nlist[d_head_list[i] + k] for k < d_n_neigh[i]. */
+typedef struct
+    {
+    hmd_tile_geom_t geom;
+    const unsigned short* d_tile_nlist;
+    const unsigned int* d_n_neigh;
+    const size_t* d_head_list;
+    unsigned int* d_nlist;
+    unsigned int N;
+    hmd_box_t box;
+    } hmd_tiles_to_rows_args_t;
+int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, void* stream);
+
+/* Pair forces from tile rows; args->d_nlist is ignored, everything else as hmd_compute_pair_forces_*. */
+int hmd_compute_pair_forces_lj_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom, const unsigned short* d_tile_nlist,
+                                     const hmd_lj_params_t* d_params, void* stream);
+int hmd_compute_pair_forces_example_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom,
+                                          const unsigned short* d_tile_nlist, const hmd_example_params_t* d_params, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

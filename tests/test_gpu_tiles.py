@@ -1,0 +1,158 @@
+"""GPU parity tests of the tile path (LDS-staged neighbor list and pair forces): the expanded tile
+rows must be the oracle's neighbor sets exactly, forces/energies/virials within 1e-6 relative (observed
+1e-10), and every output of the row-based build (n_neigh, Nmax growth, last_pos) must be identical."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402
+from test_gpu_kernels import K, A, liquid, boxes, _rel_err, F_RTOL  # noqa: E402,F401
+
+
+def tile_nlist(K, A, pos_t, N, gbox, obox, r_cut, r_buff, n_ghost=0, ghost_width=(0, 0, 0), capacity=None):
+    _, _, rmax, _ = orc.update_rlist(np.asarray(r_cut, dtype=float), r_buff)
+    dim = orc.cell_dimensions(obox, rmax + r_buff, 1, ghost_width, 3)
+    cl = K.cell_list_auto(pos_t, N, n_ghost, gbox, dim, ghost_width, want_idx=True)
+    adj = torch.as_tensor(orc.cell_adj(dim, 1, 3).view(np.int32), device="cuda")
+    tl = K.nlist_tiles(pos_t, N, gbox, r_cut, r_buff, cl, adj, capacity=capacity)
+    return tl, cl, dim
+
+
+def expanded_sets(K, tl, N, gbox):
+    nlist = K.tiles_to_rows(tl, N, gbox)
+    return orc.neighbor_sets(tl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nlist.cpu().numpy().view(np.uint32),
+                             tl["head"].cpu().numpy().view(np.uint64)[:N])
+
+
+@pytest.mark.parametrize("n,ntypes", [(9, 1), (12, 1), (13, 2), (16, 2), (40, 1)])
+def test_tile_neighbor_sets_match_oracle(K, A, n, ntypes):
+    # 9 -> 3 cells per side (every region wraps onto the whole box), 13 -> odd grid (4 cells, last block half empty)
+    xyz, typ, L = liquid(n, ntypes=ntypes)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, -1.0]]
+    pos = orc.pack_pos(xyz, typ)
+    ref = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=True)
+    tl, _, dim = tile_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, r_cut, 0.4)
+    assert np.array_equal(tl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"])
+    assert np.array_equal(tl["Nmax"].cpu().numpy().view(np.uint32), ref["Nmax"])
+    got = expanded_sets(K, tl, N, gbox)
+    want = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    for i in range(N):
+        assert np.array_equal(got[i], want[i]), i
+    assert np.array_equal(tl["last_pos"].cpu().numpy()[:N], pos)
+
+
+def test_tile_triclinic_box(K, A):
+    rng = np.random.default_rng(9)
+    L, tilt = (14.0, 12.0, 13.0), dict(xy=0.2, xz=-0.1, yz=0.15)
+    gbox, obox = A.Box.from_L(*L, **tilt), orc.Box.from_L(*L, **tilt)
+    N = 1500
+    f = rng.random((N, 3)) - 0.5
+    xyz = np.stack([f[:, 0] * L[0] + tilt["xy"] * f[:, 1] * L[1] + tilt["xz"] * f[:, 2] * L[2],
+                    f[:, 1] * L[1] + tilt["yz"] * f[:, 2] * L[2], f[:, 2] * L[2]], 1)
+    pos = orc.pack_pos(xyz, np.zeros(N, int))
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.3, storage_full=True)
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, _, _ = tile_nlist(K, A, pos_t, N, gbox, obox, [[2.0]], 0.3)
+    got, want = expanded_sets(K, tl, N, gbox), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    half = orc.nlist_binned(pos, N, obox, [[2.0]], 0.3, storage_full=False)
+    # random gas: clip the force of near-overlapping pairs out of the comparison by using a soft potential
+    F_ref, V_ref = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], [(2.0, 2.0)], [[4.0]],
+                                   third_law=True, compute_virial=True)
+    F, V = K.pair_forces_tiles("example", pos_t, N, gbox, tl, [(2.0, 2.0)], [[4.0]], compute_virial=True)
+    assert _rel_err(F.cpu().numpy(), F_ref) < F_RTOL * 1e-4
+    assert _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
+
+
+def test_tile_ghost_layer_non_periodic_box(K, A):
+    """Local box of a decomposed run: non-periodic in x, ghosts (index >= N) in the padded cells."""
+    rng = np.random.default_rng(21)
+    L = (12.0, 13.0, 14.0)
+    gw = (2.4, 0.0, 0.0)
+    N, ng = 1800, 700
+    own = (rng.random((N, 3)) - 0.5) * np.array(L)
+    gh = (rng.random((ng, 3)) - 0.5) * np.array(L)
+    gh[:, 0] = np.where(rng.random(ng) < 0.5, L[0] / 2 + rng.random(ng) * gw[0], -L[0] / 2 - rng.random(ng) * gw[0])
+    xyz = np.concatenate([own, gh])
+    gbox, obox = boxes(A, L, periodic=(0, 1, 1))
+    pos = orc.pack_pos(xyz, np.zeros(len(xyz), int))
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.4, storage_full=True, n_ghost=ng, ghost_width=gw)
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, _, _ = tile_nlist(K, A, pos_t, N, gbox, obox, [[2.0]], 0.4, n_ghost=ng, ghost_width=gw)
+    got, want = expanded_sets(K, tl, N, gbox), orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    F_ref, _ = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(1.5, 2.0)], [[4.0]],
+                               third_law=False, compute_virial=False)
+    F, _ = K.pair_forces_tiles("example", pos_t, N, gbox, tl, [(1.5, 2.0)], [[4.0]], compute_virial=False)
+    assert _rel_err(F.cpu().numpy()[:N], F_ref[:N]) < F_RTOL * 1e-4
+
+
+@pytest.mark.parametrize("shift_mode", [0, 1, 2])
+@pytest.mark.parametrize("ntypes", [1, 2])
+def test_tile_lj_forces_match_oracle(K, A, shift_mode, ntypes):
+    xyz, typ, L = liquid(14, ntypes=ntypes, seed=3 + ntypes)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    if ntypes == 1:
+        r_cut, params, ron = [[2.5]], [orc.lj_params(1.0, 1.0)], [[2.0]]
+    else:
+        r_cut = [[2.5, 2.0], [2.0, 2.2]]
+        params = [orc.lj_params(1.0, 1.0), orc.lj_params(0.8, 1.5), orc.lj_params(0.8, 1.5), orc.lj_params(0.88, 0.5)]
+        ron = [[2.0, 1.5], [1.5, 2.4]]
+    rcutsq, ronsq = np.square(r_cut), np.square(ron)
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, _, _ = tile_nlist(K, A, pos_t, N, gbox, obox, r_cut, 0.4)
+    half = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=False)
+    F_ref, V_ref = orc.pair_forces(orc.EV_LJ, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], params, rcutsq,
+                                   ronsq, shift_mode=shift_mode, third_law=True, compute_virial=True)
+    for tpp in (4, 8, 16):
+        F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, ronsq, shift_mode=shift_mode, compute_virial=True, tpp=tpp)
+        assert _rel_err(F.cpu().numpy()[:, :3], F_ref[:, :3]) < F_RTOL * 1e-4
+        assert _rel_err(F.cpu().numpy()[:, 3], F_ref[:, 3]) < F_RTOL * 1e-4
+        assert _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
+    F2, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, ronsq, shift_mode=shift_mode, compute_virial=False)
+    assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
+
+
+def test_tile_path_limits_are_reported(K, A):
+    gbox, _ = boxes(A, 5.0)
+    xyz = (np.random.default_rng(1).random((50, 3)) - 0.5) * 5.0
+    pos_t = torch.from_numpy(orc.pack_pos(xyz, np.zeros(50, int))).cuda()
+    cl = K.cell_list_auto(pos_t, 50, 0, gbox, (2, 2, 2), want_idx=True)
+    with pytest.raises(A.KernelError, match="at least 3 cells"):
+        K.tile_geom(cl, gbox)
+    # a tile smaller than the densest region: the build reports it instead of writing out of bounds
+    xyz, typ, L = liquid(12)
+    gbox, obox = boxes(A, L)
+    pos_t = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
+    with pytest.raises(A.KernelError, match="capacity"):
+        tile_nlist(K, A, pos_t, len(xyz), gbox, obox, [[2.5]], 0.4, capacity=600)
+
+
+def test_tile_forces_after_particles_wrap_between_builds(K, A):
+    """Between two builds the integrator wraps particles that leave the box: they jump by a box vector
+    while keeping their cell-list slot.  The tile kernel must see them in the right image."""
+    xyz, typ, L = liquid(12, seed=8)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, cl, dim = tile_nlist(K, A, pos_t, N, gbox, obox, [[2.5]], 0.4)
+    nlist = K.tiles_to_rows(tl, N, gbox)
+    rng = np.random.default_rng(3)
+    moved = xyz + rng.normal(0, 0.05, xyz.shape)
+    near = np.abs(xyz) > L / 2 - 0.45         # push the ones near a face across it
+    moved = np.where(near, moved + np.sign(xyz) * 0.5, moved)
+    wrapped = (moved + L / 2) % L - L / 2
+    assert (np.abs(wrapped - moved) > 1).any()
+    pos2_t = torch.from_numpy(orc.pack_pos(wrapped, typ)).cuda()
+    P = [orc.lj_params(1.0, 1.0)]
+    F_rows, V_rows = K.pair_forces("lj", pos2_t, N, gbox, tl["n_neigh"], nlist, tl["head"], P, [[6.25]], compute_virial=True)
+    F_tile, V_tile = K.pair_forces_tiles("lj", pos2_t, N, gbox, tl, P, [[6.25]], compute_virial=True)
+    assert _rel_err(F_tile.cpu().numpy(), F_rows.cpu().numpy()) < F_RTOL * 1e-4
+    assert _rel_err(V_tile.cpu().numpy(), V_rows.cpu().numpy()) < F_RTOL * 1e-4
