@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
         {
         const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
         const int hc[3] = {(int)(cell % a.ci.w), (int)((cell / a.ci.w) % a.ci.h), (int)(cell / (a.ci.w * a.ci.h))};
-        const int c0[3] = {hc[0] & ~1, hc[1] & ~1, hc[2] & ~1};
+        const int c0[3] = {hc[0] - hc[0] % hmd::TB_X, hc[1] - hc[1] % hmd::TB_Y, hc[2] - hc[2] % hmd::TB_Z};
         int rimg[3];
-        const int rcell = hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg);
+        const int rcell = (int)lane < hmd::TL_RC ? hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg) : -1;
         const unsigned int rsize = rcell >= 0 ? min(a.d_cell_size[rcell], a.cli.w) : 0u;
         const unsigned int rincl = hmd::tile_wave_scan(rsize, (int)lane);
         // d_tile_overflow[0]: a region outgrew the tile; [1]: largest region population seen (what the
@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
                 int diff = ac[d] - hc[d];
                 if (a.box.periodic[d])
                     diff = diff > 1 ? diff - dim[d] : (diff < -1 ? diff + dim[d] : diff);
-                r[d] = min(max(hc[d] - c0[d] + diff + 1, 0), 3);
+                r[d] = hc[d] - c0[d] + diff + 1;
                 }
-            rc = (unsigned int)((r[2] * 4 + r[1]) * 4 + r[0]);
+            rc = (unsigned int)hmd::tile_rc(min(max(r[0], 0), hmd::TR_X - 1), min(max(r[1], 0), hmd::TR_Y - 1), min(max(r[2], 0), hmd::TR_Z - 1));
             }
         s_tileoff[lane] = __shfl(rincl - rsize, (int)rc);
         }

@@ -17,17 +17,17 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
     int cx0, cy0, cz0;
     tile_setup(a.geom, a.box, T, cx0, cy0, cz0);
     __syncthreads();
-    if (T.off[TL_RC] > a.geom.capacity)
+    if (T.off[64] > a.geom.capacity)
         return;
     tile_stage<false, true, false>(a.geom, a.box, T, nullptr, nullptr, nullptr, nullptr, tidx, nullptr);
     __syncthreads();
     const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    for (unsigned int hc = 0; hc < 8; hc++)
+    for (unsigned int hc = 0; hc < (unsigned int)TL_NH; hc++)
         {
-        const int hx = hc & 1, hy = (hc >> 1) & 1, hz = hc >> 2;
+        const int hx = hc % TB_X, hy = (hc / TB_X) % TB_Y, hz = hc / (TB_X * TB_Y);
         if (!tile_is_home(a.geom, cx0, cy0, cz0, hx, hy, hz))
             continue;
-        const unsigned int rc_home = ((hz + 1) * 4 + (hy + 1)) * 4 + (hx + 1);
+        const unsigned int rc_home = tile_home_rc((int)hc);
         for (unsigned int lh = T.off[rc_home] + wave; lh < T.off[rc_home + 1]; lh += 4)
             {
             const unsigned int i = tidx[lh];

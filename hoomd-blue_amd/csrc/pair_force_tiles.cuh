@@ -20,8 +20,13 @@ struct pft_home_t
     unsigned int lh;  // candidate number of the particle itself
     };
 
+constexpr int PFT_THREADS = 256;              // 4 waves share one staged region
+constexpr int PFT_WAVES = PFT_THREADS / 64;
+constexpr int PFT_CELLS = (TL_RC + PFT_WAVES - 1) / PFT_WAVES; // region cells staged by one wave
+constexpr int PFT_BATCH = (PFT_CELLS + 1) / 2;                  // ... in two rounds of this many loads in flight
+
 template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE>
-__global__ void __launch_bounds__(TL_THREADS)
+__global__ void __launch_bounds__(PFT_THREADS)
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
     {
     typedef typename Ev::param_type param_t;
@@ -33,7 +38,7 @@ __global__ void __launch_bounds__(TL_THREADS)
     double* txyz = reinterpret_cast<double*>(s_dyn);
     pft_home_t* s_home = reinterpret_cast<pft_home_t*>(txyz + 3 * ((size_t)cap + 1));
     const unsigned int np = a.ntypes * a.ntypes;
-    double* s_rcutsq = reinterpret_cast<double*>(s_home + 8 * g.cli.w);
+    double* s_rcutsq = reinterpret_cast<double*>(s_home + TL_NH * g.cli.w);
     double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
     unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
@@ -50,42 +55,42 @@ __global__ void __launch_bounds__(TL_THREADS)
             ronsq0 = a.d_ronsq[0];
         }
     else
-        for (unsigned int t = threadIdx.x; t < np; t += TL_THREADS)
+        for (unsigned int t = threadIdx.x; t < np; t += PFT_THREADS)
             {
             s_params[t] = d_params[t];
             s_rcutsq[t] = a.d_rcutsq[t];
             s_ronsq[t] = (SHIFT == 2) ? a.d_ronsq[t] : 0.0;
             }
     if (threadIdx.x == 0)
-        s_next = TL_THREADS / TPP;
+        s_next = PFT_THREADS / TPP;
     __syncthreads();
-    const unsigned int total = T.off[TL_RC];
+    const unsigned int total = T.off[64];
     if (total > cap || total == 0)
         return;
 
     // ---- home particles: members of the (up to 8) home cells, numbered consecutively ----
-    unsigned int hbeg[8], hcum[9];
+    unsigned int hbeg[TL_NH], hcum[TL_NH + 1];
     hcum[0] = 0;
 #pragma unroll
-    for (int hc = 0; hc < 8; hc++)
+    for (int hc = 0; hc < TL_NH; hc++)
         {
-        const int hx = hc & 1, hy = (hc >> 1) & 1, hz = hc >> 2;
-        const unsigned int rc = ((hz + 1) * 4 + (hy + 1)) * 4 + (hx + 1);
+        const int hx = hc % TB_X, hy = (hc / TB_X) % TB_Y, hz = hc / (TB_X * TB_Y);
+        const unsigned int rc = tile_home_rc(hc);
         const bool home = tile_is_home(g, cx0, cy0, cz0, hx, hy, hz);
         hbeg[hc] = T.off[rc];
         hcum[hc + 1] = hcum[hc] + (home ? T.off[rc + 1] - T.off[rc] : 0u);
         }
-    const unsigned int H = hcum[8];
+    const unsigned int H = hcum[TL_NH];
     auto home_local = [&](unsigned int h, unsigned int& rc_home) -> unsigned int
     {
         unsigned int lh = 0;
         rc_home = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++)
+        for (int c = 0; c < TL_NH; c++)
             if (h >= hcum[c] && h < hcum[c + 1])
                 {
                 lh = hbeg[c] + (h - hcum[c]);
-                rc_home = ((((c >> 2) + 1) * 4 + (((c >> 1) & 1) + 1)) * 4 + ((c & 1) + 1));
+                rc_home = tile_home_rc(c);
                 }
         return lh;
     };
@@ -102,19 +107,19 @@ __global__ void __launch_bounds__(TL_THREADS)
 #pragma unroll
     for (int round = 0; round < 2; round++)
         {
-        const unsigned int rc0 = wave * 16 + round * 8;
-        unsigned int idx[8];
-        bool on[8];
+        const unsigned int rc0 = wave * PFT_CELLS + round * PFT_BATCH;
+        unsigned int idx[PFT_BATCH];
+        bool on[PFT_BATCH];
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < PFT_BATCH; q++)
             {
             const unsigned int rc = rc0 + q;
-            on[q] = lane < T.off[rc + 1] - T.off[rc];
+            on[q] = rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC) && lane < T.off[rc + 1] - T.off[rc];
             idx[q] = on[q] ? g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + lane] : 0u;
             }
-        double4 p[8];
+        double4 p[PFT_BATCH];
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < PFT_BATCH; q++)
             p[q] = hmd_ld4(a.d_pos + idx[q]);
         if (round == 0 && my_h < H)
             {
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(TL_THREADS)
             s_home[my_h] = e;
             }
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < PFT_BATCH; q++)
             {
             const unsigned int rc = rc0 + q;
             if (on[q])
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(TL_THREADS)
             }
         }
     // the uncommon leftovers: cells with more than 64 members, blocks with more than 256 home particles
-    for (unsigned int rc = wave * 16; rc < wave * 16 + 16; rc++)
+    for (unsigned int rc = wave * PFT_CELLS; rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC); rc++)
         {
         const unsigned int size = T.off[rc + 1] - T.off[rc];
         for (unsigned int k = lane + 64; k < size; k += 64)
@@ -165,7 +170,7 @@ __global__ void __launch_bounds__(TL_THREADS)
                 ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
             }
         }
-    for (unsigned int h = threadIdx.x + TL_THREADS; h < H; h += TL_THREADS)
+    for (unsigned int h = threadIdx.x + PFT_THREADS; h < H; h += PFT_THREADS)
         {
         unsigned int rc_home;
         const unsigned int lh = home_local(h, rc_home);
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(TL_THREADS)
 
 template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned int ntypes, unsigned int cell_Nmax)
     {
-    size_t b = ((size_t)cap + 1) * 24 + (size_t)8 * cell_Nmax * sizeof(pft_home_t);
+    size_t b = ((size_t)cap + 1) * 24 + (size_t)TL_NH * cell_Nmax * sizeof(pft_home_t);
     if (ntypes > 1)
         b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + cap + 1;
     return (b + 15) / 16 * 16;
@@ -291,7 +296,7 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
                 const typename Ev::param_type* d_params, unsigned int tpp, hipStream_t s)
     {
     const size_t lds = pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w);
-    const dim3 grid(tile_num_blocks(g.ci)), block(TL_THREADS);
+    const dim3 grid(tile_num_blocks(g.ci)), block(PFT_THREADS);
 #define HMD_PFT_LAUNCH(TPPV)                                                                                               \
     if (a.ntypes == 1)                                                                                                     \
         {                                                                                                                  \

@@ -7,7 +7,7 @@
 // images shifted by the box vectors up front -- and all pair work afterwards reads LDS: no
 // minimum-image arithmetic per pair (hoomd/BoxDim.h:306-325) and no scattered global loads.
 //
-// Region cell rc = (rz*4 + ry)*4 + rx, rx,ry,rz in 0..3, is grid cell (2*bx - 1 + rx, ...), wrapped
+// Region cell rc = (rz*4 + ry)*4 + rx (for a 4x4x4 region) is grid cell (2*bx - 1 + rx, ...), wrapped
 // along periodic directions (needs >= 3 cells there: then the 3x3x3 neighborhood of any home cell
 // never holds two images of one cell) and empty outside the grid otherwise.  Candidate numbers are
 // off[rc] + slot: the exclusive prefix sum of the region's cell sizes plus the slot in the cell list.
@@ -19,11 +19,29 @@
 namespace hmd
     {
 constexpr int TL_THREADS = 256;
-constexpr int TL_RC = 64;
+// home cells per block along x, y, z and the region around them (one cell wider on every side)
+#ifndef HMD_TILE_BZ
+#define HMD_TILE_BZ 2
+#endif
+constexpr int TB_X = 2, TB_Y = 2, TB_Z = HMD_TILE_BZ;
+constexpr int TR_X = TB_X + 2, TR_Y = TB_Y + 2, TR_Z = TB_Z + 2;
+constexpr int TL_RC = TR_X * TR_Y * TR_Z; // region cells, at most 64 (one wave scans them)
+constexpr int TL_NH = TB_X * TB_Y * TB_Z; // home cells
+static_assert(TL_RC <= 64, "the region must fit one wave");
+
+// region cell number of region coordinates, and of home cell hc = (hz*TB_Y + hy)*TB_X + hx
+__host__ __device__ constexpr int tile_rc(int rx, int ry, int rz)
+    {
+    return (rz * TR_Y + ry) * TR_X + rx;
+    }
+__host__ __device__ constexpr int tile_home_rc(int hc)
+    {
+    return tile_rc(hc % TB_X + 1, (hc / TB_X) % TB_Y + 1, hc / (TB_X * TB_Y) + 1);
+    }
 
 struct tile_tables
     {
-    unsigned int off[TL_RC + 1]; // exclusive prefix of the region's cell sizes; off[64] = total
+    unsigned int off[65];        // exclusive prefix of the region's cell sizes; off[TL_RC..64] = total
     int cell[TL_RC];             // grid cell of a region cell, -1 when outside a non-periodic grid
     // centre of the region cell in fractional box coordinates, from its UNWRAPPED grid coordinate
     // (below 0 or above 1 for a periodic image): a member at fraction f is seen in image rint(fc - f)
@@ -38,14 +56,14 @@ __device__ __forceinline__ unsigned int tile_xcd_remap(unsigned int b, unsigned 
 
 static inline unsigned int tile_num_blocks(const hmd_index3d_t& ci)
     {
-    return ((ci.w + 1) / 2) * ((ci.h + 1) / 2) * ((ci.d + 1) / 2);
+    return ((ci.w + TB_X - 1) / TB_X) * ((ci.h + TB_Y - 1) / TB_Y) * ((ci.d + TB_Z - 1) / TB_Z);
     }
 
 // Region cell t (0..63) of the block whose first home cell is (cx0,cy0,cz0): its grid cell, or -1
 // when it lies outside a non-periodic grid, and the periodic image it is seen in.
 __device__ __forceinline__ int tile_region_cell(const hmd_index3d_t& ci, const hmd_box_t& box, int cx0, int cy0, int cz0, int t, int (&img)[3])
     {
-    int c[3] = {cx0 - 1 + (t & 3), cy0 - 1 + ((t >> 2) & 3), cz0 - 1 + (t >> 4)};
+    int c[3] = {cx0 - 1 + t % TR_X, cy0 - 1 + (t / TR_X) % TR_Y, cz0 - 1 + t / (TR_X * TR_Y)};
     const int dim[3] = {(int)ci.w, (int)ci.h, (int)ci.d};
     bool valid = true;
 #pragma unroll
@@ -96,25 +114,28 @@ __device__ __forceinline__ unsigned int tile_wave_scan(unsigned int v, int lane)
 // first home cell.  Callers __syncthreads() afterwards.
 __device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_box_t& box, tile_tables& T, int& cx0, int& cy0, int& cz0)
     {
-    const unsigned int nbx = (g.ci.w + 1) / 2, nby = (g.ci.h + 1) / 2;
+    const unsigned int nbx = (g.ci.w + TB_X - 1) / TB_X, nby = (g.ci.h + TB_Y - 1) / TB_Y;
     const unsigned int vb = tile_xcd_remap(blockIdx.x, gridDim.x);
-    cx0 = 2 * (int)(vb % nbx);
-    cy0 = 2 * (int)((vb / nbx) % nby);
-    cz0 = 2 * (int)(vb / (nbx * nby));
-    if (threadIdx.x < TL_RC)
+    cx0 = TB_X * (int)(vb % nbx);
+    cy0 = TB_Y * (int)((vb / nbx) % nby);
+    cz0 = TB_Z * (int)(vb / (nbx * nby));
+    if (threadIdx.x < 64)
         {
         const int t = (int)threadIdx.x;
         int img[3];
-        const int cell = tile_region_cell(g.ci, box, cx0, cy0, cz0, t, img);
+        const int cell = t < TL_RC ? tile_region_cell(g.ci, box, cx0, cy0, cz0, t, img) : -1;
         const unsigned int size = cell >= 0 ? min(g.d_cell_size[cell], g.cli.w) : 0u;
-        T.fcx[t] = (cx0 - 1 + (t & 3) + 0.5) / (double)g.ci.w;
-        T.fcy[t] = (cy0 - 1 + ((t >> 2) & 3) + 0.5) / (double)g.ci.h;
-        T.fcz[t] = (cz0 - 1 + (t >> 4) + 0.5) / (double)g.ci.d;
-        T.cell[t] = cell;
         const unsigned int incl = tile_wave_scan(size, t);
         T.off[t] = incl - size;
-        if (t == TL_RC - 1)
-            T.off[TL_RC] = incl;
+        if (t == 63)
+            T.off[64] = incl;
+        if (t < TL_RC)
+            {
+            T.fcx[t] = (cx0 - 1 + t % TR_X + 0.5) / (double)g.ci.w;
+            T.fcy[t] = (cy0 - 1 + (t / TR_X) % TR_Y + 0.5) / (double)g.ci.h;
+            T.fcz[t] = (cz0 - 1 + t / (TR_X * TR_Y) + 0.5) / (double)g.ci.d;
+            T.cell[t] = cell;
+            }
         }
     }
 
@@ -139,6 +160,7 @@ __device__ __forceinline__ void tile_place(const hmd_box_t& box, const tile_tabl
 // region cell that holds candidate v (off[rc] <= v < off[rc+1]); empty cells are skipped
 __device__ __forceinline__ unsigned int tile_find_cell(const tile_tables& T, unsigned int v)
     {
+    // off[] has 65 entries whatever TL_RC is; the tail repeats the total, so v < total never lands there
     unsigned int lo = 0;
 #pragma unroll
     for (unsigned int s = 32; s > 0; s >>= 1)
@@ -159,7 +181,7 @@ template<bool WITH_POS, bool WITH_IDX, bool WITH_TYPE>
 __device__ __forceinline__ void tile_stage(const hmd_tile_geom_t& g, const hmd_box_t& box, const tile_tables& T, const hmd_scalar4* d_pos,
                                            double* tx, double* ty, double* tz, unsigned int* tidx, unsigned char* ttype)
     {
-    const unsigned int total = T.off[TL_RC];
+    const unsigned int total = T.off[64];
     for (unsigned int v = threadIdx.x; v < total; v += TL_THREADS)
         {
         const unsigned int rc = tile_find_cell(T, v);
