@@ -74,6 +74,87 @@ __global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
     a.d_accel[idx] = acc;
     }
 
+// step two of t, step one of t+1 and the distance check in one pass (same arithmetic, same order, as the
+// three kernels they replace: step_two_kernel, step_one_kernel, nlist_check_kernel)
+__global__ void publish_only_kernel(const unsigned int* d_result, unsigned long long* d_published, unsigned int stamp)
+    {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(d_published, ((unsigned long long)stamp << 32) | (unsigned long long)(*d_result), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_step_kernel(hmd_fused_step_args_t a)
+    {
+    const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (g < a.one.group_size)
+        {
+        const unsigned int idx = a.one.d_group_members ? a.one.d_group_members[g] : g;
+        const double4 f = hmd_ld4(a.two.d_net_force + idx);
+        const double4 v = hmd_ld4(a.one.d_vel + idx);
+        const double4 p = hmd_ld4(a.one.d_pos + idx);
+        // ---- step two (t) ----
+        const double minv = 1.0 / v.w;
+        hmd_scalar3 acc;
+        acc.x = HMD_MUL(f.x, minv);
+        acc.y = HMD_MUL(f.y, minv);
+        acc.z = HMD_MUL(f.z, minv);
+        const double hdt = HMD_MUL(0.5, a.two.deltaT);
+        double vx = HMD_ADD(HMD_MUL(v.x, a.two.rescale_factor), HMD_MUL(hdt, acc.x));
+        double vy = HMD_ADD(HMD_MUL(v.y, a.two.rescale_factor), HMD_MUL(hdt, acc.y));
+        double vz = HMD_ADD(HMD_MUL(v.z, a.two.rescale_factor), HMD_MUL(hdt, acc.z));
+        a.two.d_accel[idx] = acc;
+        // ---- step one (t+1) ----
+        vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), a.one.rescale_factor);
+        vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), a.one.rescale_factor);
+        vz = HMD_MUL(HMD_ADD(vz, HMD_MUL(HMD_MUL(0.5, acc.z), a.one.deltaT)), a.one.rescale_factor);
+        double x = HMD_ADD(p.x, HMD_MUL(a.one.deltaT, vx));
+        double y = HMD_ADD(p.y, HMD_MUL(a.one.deltaT, vy));
+        double z = HMD_ADD(p.z, HMD_MUL(a.one.deltaT, vz));
+        hmd_int3 img = a.one.d_image[idx];
+        hmd_wrap(a.one.box, x, y, z, img.x, img.y, img.z);
+        hmd_st4(a.one.d_pos + idx, x, y, z, p.w);
+        hmd_st4(a.one.d_vel + idx, vx, vy, vz, v.w);
+        a.one.d_image[idx] = img;
+        // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
+        if (CHECK)
+            {
+            const double4 last = hmd_ld4(a.check.d_last_pos + idx);
+            double dx = HMD_SUB(x, HMD_MUL(a.check.lambda.x, last.x));
+            double dy = HMD_SUB(y, HMD_MUL(a.check.lambda.y, last.y));
+            double dz = HMD_SUB(z, HMD_MUL(a.check.lambda.z, last.z));
+            hmd_min_image<ORTHO>(a.check.box, dx, dy, dz);
+            const double rmin = a.check.d_rcut_max[hmd_double_as_uint(p.w)];
+            const double rmax = HMD_ADD(rmin, a.check.r_buff);
+            const double delta_max = HMD_SUB(HMD_MUL(rmax, a.check.lambda_min), rmin) / 2.0;
+            const double maxsq = (delta_max > 0) ? HMD_MUL(delta_max, delta_max) : 0.0;
+            moved = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz)) >= maxsq;
+            }
+        }
+    if (CHECK)
+        {
+        if (__ballot(moved) && (threadIdx.x & 63) == 0)
+            atomicMax(a.check.d_result, a.check.checkn);
+        if (a.check.d_published)
+            {
+            // the last workgroup to get here has seen every atomicMax above (fence + counter)
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0)
+                {
+                const unsigned int done = atomicAdd(a.d_block_counter, 1u);
+                if (done == gridDim.x - 1)
+                    {
+                    const unsigned int r = __hip_atomic_load(a.check.d_result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *a.d_block_counter = 0u;
+                    const unsigned long long w = ((unsigned long long)a.check.stamp << 32) | (unsigned long long)r;
+                    __hip_atomic_store(a.check.d_published, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
+    }
+
 __global__ void __launch_bounds__(256) accel_kernel(hmd_scalar3* d_accel, const hmd_scalar4* d_vel, const hmd_scalar4* d_nf, unsigned int N)
     {
     const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,6 +308,42 @@ extern "C" int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* s
     if (args->group_size == 0)
         return HMD_OK;
     hipLaunchKernelGGL(step_two_kernel, dim3(hmd_div_up(args->group_size, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: args is NULL");
+    const hmd_fused_step_args_t& a = *args;
+    HMD_REQUIRE(a.two.d_vel && a.two.d_accel && a.two.d_net_force && a.one.d_pos && a.one.d_vel && a.one.d_accel && a.one.d_image,
+                HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: pos, vel, accel, image and net_force are required");
+    HMD_REQUIRE(a.two.d_vel == a.one.d_vel && a.two.d_accel == a.one.d_accel && a.two.d_group_members == a.one.d_group_members
+                    && a.two.group_size == a.one.group_size,
+                HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: both halves must act on the same arrays and group");
+    HMD_REQUIRE(!a.one.use_limit, HMD_ERR_UNSUPPORTED, "hmd_nve_step_two_one_check: the displacement limit needs the separate step-one driver");
+    const bool check = a.check.d_result != nullptr;
+    if (check)
+        {
+        HMD_REQUIRE(a.check.d_last_pos && a.check.d_rcut_max, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nve_step_two_one_check: the check needs last_pos and rcut_max");
+        HMD_REQUIRE(a.one.d_group_members == nullptr && a.one.group_size == a.check.N, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nve_step_two_one_check: the check needs the group of all particles");
+        HMD_REQUIRE(!a.check.d_published || a.d_block_counter, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nve_step_two_one_check: publishing needs d_block_counter");
+        }
+    if (a.one.group_size == 0)
+        {
+        if (check && a.check.d_published)
+            hipLaunchKernelGGL(publish_only_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a.check.d_result, a.check.d_published, a.check.stamp);
+        return hmd_launch_status();
+        }
+    const dim3 grid(hmd_div_up(a.one.group_size, 256));
+    if (!check)
+        hipLaunchKernelGGL((fused_step_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (hmd_box_is_ortho(a.check.box))
+        hipLaunchKernelGGL((fused_step_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((fused_step_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return hmd_launch_status();
     }
 

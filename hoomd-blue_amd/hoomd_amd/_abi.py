@@ -151,6 +151,10 @@ class PackPosArgs(C.Structure):
                 ("n_send", u32)]
 
 
+class FusedStepArgs(C.Structure):
+    _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs), ("d_block_counter", vp)]
+
+
 class TileGeom(C.Structure):
     _fields_ = [("d_cell_size", vp), ("d_cell_idx", vp), ("ci", Index3D), ("cli", Index2D), ("capacity", u32)]
 
@@ -195,6 +199,7 @@ _SIGNATURES = {
     "hmd_build_rtag": (C.c_int, [vp, vp, u32, vp]),
     "hmd_make_ghost_exchange_plan": (C.c_int, [C.POINTER(GhostPlanArgs), vp]),
     "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
+    "hmd_nve_step_two_one_check": (C.c_int, [C.POINTER(FusedStepArgs), vp]),
     "hmd_nlist_tiles_supported": (C.c_int, [C.POINTER(Index3D), C.POINTER(Box), u32, u32, C.POINTER(u32)]),
     "hmd_compute_nlist_tiles": (C.c_int, [C.POINTER(NlistTilesArgs), vp]),
     "hmd_nlist_tiles_to_rows": (C.c_int, [C.POINTER(TilesToRowsArgs), vp]),

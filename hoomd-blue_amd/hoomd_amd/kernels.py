@@ -296,6 +296,34 @@ def step_two(vel, accel, net_force, dt, rescale=1.0, group=None):
     check(_abi.lib.hmd_nvt_rescale_step_two(C.byref(a), _stream(vel)), "hmd_nvt_rescale_step_two")
 
 
+def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, rescale_one=1.0, group=None, last_pos=None, rcut_max=None,
+               r_buff=0.0, checkn=1, publish=False):
+    """hmd_nve_step_two_one_check; returns (flag word, published 64-bit word) when the check is requested."""
+    dev = pos.device
+    a = _abi.FusedStepArgs()
+    n = pos.shape[0] if group is None else group.numel()
+    a.two.d_vel, a.two.d_accel, a.two.d_group_members, a.two.d_net_force = ptr(vel), ptr(accel), ptr(group), ptr(net_force)
+    a.two.group_size, a.two.deltaT, a.two.rescale_factor = n, float(dt), float(rescale_two)
+    a.one.d_pos, a.one.d_vel, a.one.d_accel, a.one.d_image, a.one.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
+    a.one.group_size, a.one.box, a.one.rescale_factor, a.one.deltaT = n, box, float(rescale_one), float(dt)
+    res = pub = counter = None
+    if last_pos is not None:
+        res = torch.zeros(1, dtype=torch.int32, device=dev)
+        rcm = torch.as_tensor(np.asarray(rcut_max, dtype=np.float64), device=dev)
+        c = a.check
+        c.d_result, c.d_last_pos, c.d_pos, c.N, c.box = ptr(res), ptr(last_pos), ptr(pos), pos.shape[0], box
+        c.d_rcut_max, c.r_buff, c.ntypes, c.lambda_min, c.lam, c.checkn = ptr(rcm), float(r_buff), rcm.numel(), 1.0, _s3((1.0, 1.0, 1.0)), checkn
+        if publish:
+            pub = torch.zeros(1, dtype=torch.int64, device=dev)
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            c.d_published, c.stamp = ptr(pub), checkn
+            a.d_block_counter = ptr(counter)
+    check(_abi.lib.hmd_nve_step_two_one_check(C.byref(a), _stream(pos)), "hmd_nve_step_two_one_check")
+    if res is None:
+        return None
+    return int(res.item()), (int(pub.item()) if pub is not None else None), (int(counter.item()) if counter is not None else None)
+
+
 def compute_accelerations(vel, net_force):
     accel = torch.zeros((vel.shape[0], 3), dtype=torch.float64, device=vel.device)
     check(_abi.lib.hmd_compute_accelerations(ptr(accel), ptr(vel), ptr(net_force), vel.shape[0], _stream(vel)),

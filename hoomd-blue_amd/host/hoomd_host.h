@@ -334,6 +334,18 @@ class ParticleData
         {
         return m_maxn;
         }
+    //! A neighbor list may ask whoever moves the particles to run its distance check in the same pass:
+    //! the hook fills the check's arguments for the positions of `timestep` and returns false to decline.
+    typedef std::function<bool(hmd_nlist_check_args_t&, uint64_t)> DisplacementCheckHook;
+    void setDisplacementCheckHook(DisplacementCheckHook h)
+        {
+        m_check_hook = h;
+        }
+    const DisplacementCheckHook& getDisplacementCheckHook() const
+        {
+        return m_check_hook;
+        }
+
     //! when a single force compute feeds the integrator its force array IS the net force
     void aliasNetForce(Scalar4* p)
         {
@@ -426,6 +438,7 @@ class ParticleData
     DeviceArray<unsigned int> m_tag, m_rtag, m_body, m_altu;
     DeviceArray<Scalar> m_charge, m_diameter, m_net_virial, m_alt1;
     Scalar4* m_net_force_alias = nullptr;
+    DisplacementCheckHook m_check_hook;
     bool m_accel_set = false;
     unsigned int m_flags = 0;
     Scalar m_external_energy = 0;
@@ -877,6 +890,8 @@ class NeighborListGPUBinned : public Compute
     void reallocatePerParticle();
     void ensureRows();
     bool tilesUsable(unsigned int& capacity);
+    void fillCheckArgs(hmd_nlist_check_args_t& a);
+    bool offerCheck(hmd_nlist_check_args_t& a, uint64_t timestep);
 
     std::shared_ptr<CellListGPU> m_cl;
     Scalar m_r_buff;
@@ -897,6 +912,8 @@ class NeighborListGPUBinned : public Compute
     std::vector<uint64_t> m_update_periods;
     std::array<Scalar, 3> m_last_L {{0, 0, 0}};
     unsigned int m_checkn = 1;
+    //! time step whose distance check was already launched by the integrator's fused pass
+    uint64_t m_prelaunched_tstep = ~0ull;
 
     std::vector<unsigned int> m_Nmax;
     DeviceArray<unsigned int> m_d_Nmax, m_conditions, m_n_neigh, m_nlist, m_flag;
@@ -1237,6 +1254,12 @@ class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
         }
     void integrateStepOne(uint64_t timestep) override;
     void integrateStepTwo(uint64_t timestep) override;
+    //! step two of `timestep` and step one of `timestep + 1` in one pass; only without thermostat / limit
+    bool canFuse() const
+        {
+        return !m_thermostat && m_limit < 0;
+        }
+    void integrateStepTwoOne(uint64_t timestep);
     void setThermostat(std::shared_ptr<Thermostat> t)
         {
         m_thermostat = t;
@@ -1254,6 +1277,7 @@ class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
     private:
     std::shared_ptr<Thermostat> m_thermostat;
     Scalar m_limit = -1;
+    DeviceArray<unsigned int> m_block_counter;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1266,6 +1290,8 @@ class IntegratorTwoStep
     ~IntegratorTwoStep();
     void update(uint64_t timestep);
     void prepRun(uint64_t timestep);
+    //! run the second half step that update() left pending (it is fused with the next first half)
+    void flush();
     void setDeltaT(Scalar dt);
     Scalar getDeltaT() const
         {
@@ -1305,6 +1331,9 @@ class IntegratorTwoStep
     std::vector<std::shared_ptr<ForceCompute>> m_forces;
     std::vector<std::shared_ptr<IntegrationMethodTwoStep>> m_methods;
     bool m_prepared = false, m_request_pressure = false;
+    bool m_pending_two = false;       // step two of m_pending_tstep has not run yet
+    uint64_t m_pending_tstep = 0;
+    bool m_fuse = true;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1328,6 +1357,11 @@ class ParticleSorter
         m_width = w;
         }
     void update(uint64_t timestep);
+    //! would update(timestep) reorder the particles?
+    bool isDue(uint64_t timestep) const
+        {
+        return m_period != 0 && timestep % m_period == 0 && timestep != m_last_sorted;
+        }
     void sortNow();
 
     private:

@@ -67,6 +67,46 @@ void TwoStepConstantVolumeGPU::integrateStepTwo(uint64_t timestep)
     abiCheck(hmd_nvt_rescale_step_two(&a, nullptr), "hmd_nvt_rescale_step_two");
     }
 
+// Step two of `timestep` fused with step one of `timestep + 1` and, when a neighbor list asks for it,
+// with the distance check of the new positions.
+void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
+    {
+    if (m_group->getNumMembersGlobal() == 0)
+        throw std::runtime_error("Empty integration group.");
+    hmd_fused_step_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.two.d_vel = m_pdata->vel();
+    a.two.d_accel = m_pdata->accel();
+    a.two.d_group_members = m_group->getIndexArray();
+    a.two.group_size = m_group->getNumMembers();
+    a.two.d_net_force = m_pdata->netForceForIntegration();
+    a.two.deltaT = m_deltaT;
+    a.two.rescale_factor = 1.0;
+    a.one.d_pos = m_pdata->pos();
+    a.one.d_vel = m_pdata->vel();
+    a.one.d_accel = m_pdata->accel();
+    a.one.d_image = m_pdata->image();
+    a.one.d_group_members = a.two.d_group_members;
+    a.one.group_size = a.two.group_size;
+    a.one.box = m_pdata->getBox().b;
+    a.one.rescale_factor = 1.0;
+    a.one.deltaT = m_deltaT;
+    const auto& hook = m_pdata->getDisplacementCheckHook();
+    if (hook && a.one.d_group_members == nullptr && a.one.group_size == m_pdata->getN())
+        {
+        if (m_block_counter.size() == 0)
+            {
+            m_block_counter.resize(1, false);
+            m_block_counter.zero();
+            }
+        if (!hook(a.check, timestep + 1))
+            std::memset(&a.check, 0, sizeof(a.check));
+        a.d_block_counter = m_block_counter.get();
+        }
+    ScopedKernelTimer t("step_two_one");
+    abiCheck(hmd_nve_step_two_one_check(&a, nullptr), "hmd_nve_step_two_one_check");
+    }
+
 // ---------------------------------------------------------------------------------------------
 IntegratorTwoStep::IntegratorTwoStep(std::shared_ptr<SystemDefinition> sysdef, Scalar deltaT)
     : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_deltaT(deltaT)
@@ -199,16 +239,51 @@ void IntegratorTwoStep::update(uint64_t timestep)
     {
     if (!m_prepared)
         prepRun(timestep);
-    for (auto& m : m_methods)
+    // One constant-volume method without thermostat: the second half of a step and the first half of the
+    // next touch the same arrays with nothing in between, so they run as one kernel.  The second half
+    // stays pending until the next update() (or flush()).
+    TwoStepConstantVolumeGPU* nve = nullptr;
+    if (m_fuse && m_methods.size() == 1)
         {
-        m->setDeltaT(m_deltaT);
-        m->integrateStepOne(timestep);
+        nve = dynamic_cast<TwoStepConstantVolumeGPU*>(m_methods[0].get());
+        if (nve && !nve->canFuse())
+            nve = nullptr;
+        }
+    if (nve && m_pending_two && m_pending_tstep + 1 == timestep)
+        {
+        nve->setDeltaT(m_deltaT);
+        nve->integrateStepTwoOne(m_pending_tstep);
+        m_pending_two = false;
+        }
+    else
+        {
+        flush();
+        for (auto& m : m_methods)
+            {
+            m->setDeltaT(m_deltaT);
+            m->integrateStepOne(timestep);
+            }
         }
     if (m_sysdef->isDomainDecomposed())
         m_sysdef->getCommunicator()->communicate(timestep + 1);
     computeNetForceGPU(timestep + 1);
+    if (nve)
+        {
+        m_pending_two = true;
+        m_pending_tstep = timestep;
+        }
+    else
+        for (auto it = m_methods.rbegin(); it != m_methods.rend(); ++it)
+            (*it)->integrateStepTwo(timestep);
+    }
+
+void IntegratorTwoStep::flush()
+    {
+    if (!m_pending_two)
+        return;
+    m_pending_two = false;
     for (auto it = m_methods.rbegin(); it != m_methods.rend(); ++it)
-        (*it)->integrateStepTwo(timestep);
+        (*it)->integrateStepTwo(m_pending_tstep);
     }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,11 +355,15 @@ void System::run(uint64_t nsteps)
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t s = 0; s < nsteps; s++)
         {
-        if (m_sorter)
+        if (m_sorter && m_sorter->isDue(m_cur_tstep))
+            {
+            m_integrator->flush(); // the pending half step reads forces in the old particle order
             m_sorter->update(m_cur_tstep);
+            }
         m_integrator->update(m_cur_tstep);
         m_cur_tstep++;
         }
+    m_integrator->flush();
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     m_last_walltime = dt;

@@ -38,6 +38,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
     m_cl->setComputeIdx(true); // the tile kernels number candidates through the index array
     m_cl->setFlagIndex();
 
+    m_pdata->setDisplacementCheckHook([this](hmd_nlist_check_args_t& a, uint64_t timestep) { return offerCheck(a, timestep); });
     m_sort_slot = m_pdata->getParticleSortSignal().connect([this]() { forceUpdate(); });
     m_box_slot = m_pdata->getBoxChangeSignal().connect([this]() { forceUpdate(); });
     m_maxn_slot = m_pdata->getMaxParticleNumberChangeSignal().connect([this]()
@@ -49,6 +50,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
 
 NeighborListGPUBinned::~NeighborListGPUBinned()
     {
+    m_pdata->setDisplacementCheckHook(nullptr);
     m_pdata->getParticleSortSignal().disconnect(m_sort_slot);
     m_pdata->getBoxChangeSignal().disconnect(m_box_slot);
     m_pdata->getMaxParticleNumberChangeSignal().disconnect(m_maxn_slot);
@@ -159,11 +161,11 @@ void NeighborListGPUBinned::resetStats()
     std::fill(m_update_periods.begin(), m_update_periods.end(), 0);
     }
 
-// hoomd/md/NeighborListGPU.cc:29-101
-bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
+// arguments of the distance check for the current positions; a fresh check number each time, so the
+// device flag never needs clearing
+void NeighborListGPUBinned::fillCheckArgs(hmd_nlist_check_args_t& a)
     {
     const auto L_g = m_pdata->getGlobalBox().getNearestPlaneDistance();
-    hmd_nlist_check_args_t a;
     std::memset(&a, 0, sizeof(a));
     a.lambda = Scalar3 {L_g[0] / m_last_L[0], L_g[1] / m_last_L[1], L_g[2] / m_last_L[2]};
     a.lambda_min = std::min(a.lambda.x, std::min(a.lambda.y, a.lambda.z));
@@ -175,16 +177,39 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
     a.d_rcut_max = m_d_rcut_max.get();
     a.r_buff = m_r_buff;
     a.ntypes = m_pdata->getNTypes();
-    a.checkn = ++m_checkn; // a fresh value each check: the flag never needs clearing
+    a.checkn = ++m_checkn;
     // the flag comes back through pinned memory that the host polls: no stream synchronisation,
     // the GPU idles only for the PCIe write plus the launch of the next kernel
-    volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
     a.d_published = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
     a.stamp = m_checkn;
+    }
+
+// The integrator offers to run the check of the positions of `timestep` inside its own pass over the
+// particles.  Accepted when needsUpdating(timestep) is going to ask for exactly this check.
+bool NeighborListGPUBinned::offerCheck(hmd_nlist_check_args_t& a, uint64_t timestep)
+    {
+    if (m_force_update || m_rcut_changed || !m_dist_check || !m_has_been_updated_once || m_r_buff < 1e-6)
+        return false;
+    if (timestep < m_last_updated_tstep + m_rebuild_check_delay || m_last_checked_tstep == timestep)
+        return false;
+    fillCheckArgs(a);
+    m_prelaunched_tstep = timestep;
+    return true;
+    }
+
+// hoomd/md/NeighborListGPU.cc:29-101
+bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
+    {
+    if (m_prelaunched_tstep == timestep)
+        m_prelaunched_tstep = ~0ull; // the fused integration pass already launched check number m_checkn
+    else
         {
+        hmd_nlist_check_args_t a;
+        fillCheckArgs(a);
         ScopedKernelTimer t("nlist_check");
         abiCheck(hmd_nlist_needs_update_check(&a, nullptr), "hmd_nlist_needs_update_check");
         }
+    volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
     unsigned long long v = 0;
     for (uint64_t spins = 0;; spins++)
         {

@@ -368,6 +368,24 @@ typedef struct
     } hmd_step_two_args_t;
 int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
 
+/* Second half of step t, first half of step t+1 and the neighbor-list distance check of the new
+   positions in ONE pass over the particles: the three reference drivers gpu_nvt_rescale_step_two
+   (hoomd/md/TwoStepConstantVolumeGPU.cu:215-260), gpu_nvt_rescale_step_one (:102-155) and
+   gpu_nlist_needs_update_check_new (hoomd/md/NeighborListGPU.cu:86-97) run back to back on the
+   same particles when nothing else happens between two time steps; results are bit-identical to
+   calling them in that order.  `two` and `one` must name the same group.  check.d_result == NULL
+   skips the check; otherwise the group must be every particle (d_group_members NULL,
+   group_size == check.N).  With check.d_published set, the last workgroup to finish publishes
+   (stamp << 32 | *d_result); d_block_counter is one zeroed word of device memory it uses. */
+typedef struct
+    {
+    hmd_step_two_args_t two;
+    hmd_step_one_args_t one;
+    hmd_nlist_check_args_t check;
+    unsigned int* d_block_counter;
+    } hmd_fused_step_args_t;
+int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, void* stream);
+
 /* a = F/m for all N particles: Integrator::computeAccelerations (hoomd/Integrator.cc:106-127),
    which the reference runs on the host; here it stays on the device. */
 int hmd_compute_accelerations(hmd_scalar3* d_accel,

@@ -483,6 +483,42 @@ def test_half_steps_bit_exact_vs_oracle(K, A):
     assert np.array_equal(acc.cpu().numpy(), orc.compute_accel(vel, nf))
 
 
+def test_fused_half_steps_and_check_match_the_separate_drivers(K, A):
+    """step two(t) + step one(t+1) + distance check in one kernel: bit-identical to the three drivers."""
+    xyz, typ, L = liquid(10, seed=15, ntypes=2)
+    N = len(xyz)
+    rng = np.random.default_rng(4)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    pos[:8, 0] = L / 2 - 1e-4
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    vel[:8, 0] = 1.0
+    accel = rng.normal(0, 5.0, (N, 3))
+    image = rng.integers(-2, 3, (N, 3)).astype(np.int32)
+    nf = np.concatenate([rng.normal(0, 7.0, (N, 3)), rng.normal(-3, 1, (N, 1))], 1)
+    last = pos.copy()
+    rcut_max = [2.5, 2.0]
+    for dt, expect_move in ((0.005, False), (0.08, True)):
+        p, v, a_, im = pos.copy(), vel.copy(), accel.copy(), image.copy()
+        orc.step_two(v, a_, nf, dt, 1.0, None)
+        orc.step_one(p, v, a_, im, obox, dt, 1.0, None)
+        tp, tv, ta, ti, tnf, tl = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image, nf, last))
+        flag, pub, counter = K.fused_step(tp, tv, ta, ti, tnf, gbox, dt, last_pos=tl, rcut_max=rcut_max, r_buff=0.4, checkn=7, publish=True)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v)
+        assert np.array_equal(ta.cpu().numpy(), a_) and np.array_equal(ti.cpu().numpy(), im)
+        want = K.nlist_check(torch.from_numpy(p).cuda(), tl, N, gbox, rcut_max, 0.4, checkn=7)
+        assert flag == want and (flag == 7) == expect_move
+        assert pub == (7 << 32) | flag and counter == 0
+    # a group, no check
+    group = rng.permutation(N)[: N // 2].astype(np.uint32)
+    p, v, a_, im = pos.copy(), vel.copy(), accel.copy(), image.copy()
+    orc.step_two(v, a_, nf, 0.005, 1.0, group)
+    orc.step_one(p, v, a_, im, obox, 0.005, 1.0, group)
+    tp, tv, ta, ti, tnf = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image, nf))
+    assert K.fused_step(tp, tv, ta, ti, tnf, gbox, 0.005, group=torch.from_numpy(group.view(np.int32)).cuda()) is None
+    assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v) and np.array_equal(ta.cpu().numpy(), a_)
+
+
 def test_sum_net_force_and_thermo(K, A):
     rng = np.random.default_rng(4)
     N = 5000
