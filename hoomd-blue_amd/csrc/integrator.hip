@@ -135,23 +135,6 @@ template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_st
         {
         if (__ballot(moved) && (threadIdx.x & 63) == 0)
             atomicMax(a.check.d_result, a.check.checkn);
-        if (a.check.d_published)
-            {
-            // the last workgroup to get here has seen every atomicMax above (fence + counter)
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0)
-                {
-                const unsigned int done = atomicAdd(a.d_block_counter, 1u);
-                if (done == gridDim.x - 1)
-                    {
-                    const unsigned int r = __hip_atomic_load(a.check.d_result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *a.d_block_counter = 0u;
-                    const unsigned long long w = ((unsigned long long)a.check.stamp << 32) | (unsigned long long)r;
-                    __hip_atomic_store(a.check.d_published, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
-            }
         }
     }
 
@@ -328,8 +311,6 @@ extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, voi
                     "hmd_nve_step_two_one_check: the check needs last_pos and rcut_max");
         HMD_REQUIRE(a.one.d_group_members == nullptr && a.one.group_size == a.check.N, HMD_ERR_INVALID_ARGUMENT,
                     "hmd_nve_step_two_one_check: the check needs the group of all particles");
-        HMD_REQUIRE(!a.check.d_published || a.d_block_counter, HMD_ERR_INVALID_ARGUMENT,
-                    "hmd_nve_step_two_one_check: publishing needs d_block_counter");
         }
     if (a.one.group_size == 0)
         {
@@ -344,6 +325,11 @@ extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, voi
         hipLaunchKernelGGL((fused_step_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((fused_step_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    // a separate one-wave kernel hands the flag to the host: making every workgroup's atomic visible to a
+    // "last workgroup" inside the big kernel would need a device-wide fence per workgroup, which costs
+    // far more across the eight XCDs than this launch
+    if (check && a.check.d_published)
+        hipLaunchKernelGGL(publish_only_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a.check.d_result, a.check.d_published, a.check.stamp);
     return hmd_launch_status();
     }
 

@@ -30,6 +30,8 @@ __global__ void __launch_bounds__(PFT_THREADS)
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
     {
     typedef typename Ev::param_type param_t;
+    if (a.d_skip_flag && *a.d_skip_flag == a.skip_value)
+        return;
     __shared__ tile_tables T;
     __shared__ unsigned int s_next;
     extern __shared__ __align__(16) unsigned char s_dyn[];

@@ -108,7 +108,8 @@ class PairArgs(C.Structure):
     _fields_ = [("d_force", vp), ("d_virial", vp), ("virial_pitch", C.c_size_t), ("N", u32), ("n_max", u32),
                 ("d_pos", vp), ("d_charge", vp), ("box", Box), ("d_n_neigh", vp), ("d_nlist", vp), ("d_head_list", vp),
                 ("d_rcutsq", vp), ("d_ronsq", vp), ("size_neigh_list", C.c_size_t), ("ntypes", u32),
-                ("block_size", u32), ("shift_mode", u32), ("compute_virial", u32), ("threads_per_particle", u32)]
+                ("block_size", u32), ("shift_mode", u32), ("compute_virial", u32), ("threads_per_particle", u32),
+                ("d_skip_flag", vp), ("skip_value", u32)]
 
 
 class ForceList(C.Structure):
@@ -152,7 +153,7 @@ class PackPosArgs(C.Structure):
 
 
 class FusedStepArgs(C.Structure):
-    _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs), ("d_block_counter", vp)]
+    _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs)]
 
 
 class TileGeom(C.Structure):

@@ -306,7 +306,7 @@ def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, resc
     a.two.group_size, a.two.deltaT, a.two.rescale_factor = n, float(dt), float(rescale_two)
     a.one.d_pos, a.one.d_vel, a.one.d_accel, a.one.d_image, a.one.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
     a.one.group_size, a.one.box, a.one.rescale_factor, a.one.deltaT = n, box, float(rescale_one), float(dt)
-    res = pub = counter = None
+    res = pub = None
     if last_pos is not None:
         res = torch.zeros(1, dtype=torch.int32, device=dev)
         rcm = torch.as_tensor(np.asarray(rcut_max, dtype=np.float64), device=dev)
@@ -315,13 +315,11 @@ def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, resc
         c.d_rcut_max, c.r_buff, c.ntypes, c.lambda_min, c.lam, c.checkn = ptr(rcm), float(r_buff), rcm.numel(), 1.0, _s3((1.0, 1.0, 1.0)), checkn
         if publish:
             pub = torch.zeros(1, dtype=torch.int64, device=dev)
-            counter = torch.zeros(1, dtype=torch.int32, device=dev)
             c.d_published, c.stamp = ptr(pub), checkn
-            a.d_block_counter = ptr(counter)
     check(_abi.lib.hmd_nve_step_two_one_check(C.byref(a), _stream(pos)), "hmd_nve_step_two_one_check")
     if res is None:
         return None
-    return int(res.item()), (int(pub.item()) if pub is not None else None), (int(counter.item()) if counter is not None else None)
+    return int(res.item()), (int(pub.item()) if pub is not None else None)
 
 
 def compute_accelerations(vel, net_force):

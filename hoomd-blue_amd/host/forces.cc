@@ -116,6 +116,13 @@ PotentialPairGPU<Ev>::PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef,
     m_ronsq.assign(np, 0.0);
     m_r_cut_nlist = std::make_shared<std::vector<Scalar>>(np, 0.0);
     m_nlist->addRCutMatrix(m_r_cut_nlist); // hoomd/md/PotentialPair.h:369-371
+    // queue the force kernel behind the distance check, predicated on "list still valid": on the steps
+    // without a rebuild (most of them) the GPU does not idle while the host reads the check's result
+    m_nlist->setSpeculationHook([this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale)
+                                {
+                                launchKernel(d_flag, stale);
+                                m_spec_tstep = timestep;
+                                });
     m_d_params.resize(np);
     m_d_rcutsq.resize(np);
     m_d_ronsq.resize(np);
@@ -124,7 +131,10 @@ PotentialPairGPU<Ev>::PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef,
 template<class Ev> PotentialPairGPU<Ev>::~PotentialPairGPU()
     {
     if (m_nlist)
+        {
+        m_nlist->setSpeculationHook(nullptr);
         m_nlist->removeRCutMatrix(m_r_cut_nlist);
+        }
     }
 
 // hoomd/md/PotentialPair.h:467-482 (symmetric assignment)
@@ -165,9 +175,18 @@ template<class Ev> Scalar PotentialPairGPU<Ev>::getROn(unsigned int typ1, unsign
 // hoomd/md/PotentialPairGPU.h:89-160
 template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     {
-    m_nlist->compute(timestep);
+    m_spec_tstep = ~0ull;
+    m_nlist->compute(timestep); // may call launchKernel() through the speculation hook
     if (m_nlist->getStorageMode() == NeighborListGPUBinned::half)
         throw std::runtime_error("PotentialPairGPU cannot handle a half neighborlist");
+    // the speculative launch stands when the list was not rebuilt at this step
+    if (!(m_spec_tstep == timestep && m_nlist->getLastBuildTimestep() != timestep))
+        launchKernel(nullptr, 0);
+    computeTailCorrection();
+    }
+
+template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value)
+    {
     if (m_tables_dirty)
         {
         m_d_params.upload(m_params.data(), m_params.size());
@@ -198,17 +217,16 @@ template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     a.threads_per_particle = m_tpp;
     if (tiles && m_tpp != 4 && m_tpp != 8 && m_tpp != 16)
         a.threads_per_particle = 0; // the tile kernel is built for 4, 8 and 16 lanes per particle
+    a.d_skip_flag = d_skip_flag;
+    a.skip_value = skip_value;
+    ScopedKernelTimer t("pair_force");
+    if (tiles)
         {
-        ScopedKernelTimer t("pair_force");
-        if (tiles)
-            {
-            const hmd_tile_geom_t g = m_nlist->getTileGeom();
-            abiCheck(Ev::launchTiles(&a, &g, m_nlist->getTileNlist().get(), m_d_params.get(), nullptr), "gpu_compute_pair_forces (tiles)");
-            }
-        else
-            abiCheck(Ev::launch(&a, m_d_params.get(), nullptr), "gpu_compute_pair_forces");
+        const hmd_tile_geom_t g = m_nlist->getTileGeom();
+        abiCheck(Ev::launchTiles(&a, &g, m_nlist->getTileNlist().get(), m_d_params.get(), nullptr), "gpu_compute_pair_forces (tiles)");
         }
-    computeTailCorrection();
+    else
+        abiCheck(Ev::launch(&a, m_d_params.get(), nullptr), "gpu_compute_pair_forces");
     }
 
 // hoomd/md/PotentialPair.h:255-341 (single rank: the per-type counts come from the type ids)

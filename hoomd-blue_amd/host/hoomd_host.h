@@ -851,6 +851,19 @@ class NeighborListGPUBinned : public Compute
         return m_tile_nlist;
         }
     hmd_tile_geom_t getTileGeom() const;
+    //! Called from compute() right after a distance check has been queued and before the host waits for
+    //! its result, with the device flag and the value it takes when the list is stale: a consumer may
+    //! queue work that is only valid for a fresh list, predicated on the flag.
+    typedef std::function<void(uint64_t, const unsigned int*, unsigned int)> SpeculationHook;
+    void setSpeculationHook(SpeculationHook h)
+        {
+        m_speculate = h;
+        }
+    //! time step of the last (re)build
+    uint64_t getLastBuildTimestep() const
+        {
+        return m_last_build_tstep;
+        }
     const DeviceArray<size_t>& getHeadList() const
         {
         return m_head_list;
@@ -914,6 +927,9 @@ class NeighborListGPUBinned : public Compute
     unsigned int m_checkn = 1;
     //! time step whose distance check was already launched by the integrator's fused pass
     uint64_t m_prelaunched_tstep = ~0ull;
+    SpeculationHook m_speculate;
+    bool m_in_compute = false;
+    uint64_t m_last_build_tstep = ~0ull;
 
     std::vector<unsigned int> m_Nmax;
     DeviceArray<unsigned int> m_d_Nmax, m_conditions, m_n_neigh, m_nlist, m_flag;
@@ -1090,7 +1106,9 @@ template<class Ev> class PotentialPairGPU : public ForceCompute
 
     protected:
     void computeForces(uint64_t timestep) override;
+    void launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value);
     void computeTailCorrection();
+    uint64_t m_spec_tstep = ~0ull; // time step whose force kernel was queued speculatively
     std::shared_ptr<NeighborListGPUBinned> m_nlist;
     unsigned int m_ntypes;
     energyShiftMode m_shift_mode = no_shift;
@@ -1277,7 +1295,6 @@ class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
     private:
     std::shared_ptr<Thermostat> m_thermostat;
     Scalar m_limit = -1;
-    DeviceArray<unsigned int> m_block_counter;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1433,6 +1450,11 @@ struct KernelTimer
         {
         m_filter = name;
         }
+    //! samples shorter than this are booked under "<name>_skipped" (launches that were predicated off)
+    void setMinMs(double ms)
+        {
+        m_min_ms = ms;
+        }
     bool enabled() const
         {
         return m_on;
@@ -1450,6 +1472,7 @@ struct KernelTimer
     private:
     bool m_on = false;
     std::string m_filter;
+    double m_min_ms = 0;
     struct Rec
         {
         std::string name;

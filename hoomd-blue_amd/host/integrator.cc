@@ -68,7 +68,7 @@ void TwoStepConstantVolumeGPU::integrateStepTwo(uint64_t timestep)
     }
 
 // Step two of `timestep` fused with step one of `timestep + 1` and, when a neighbor list asks for it,
-// with the distance check of the new positions.
+// with the distance check of the new positions (those of time step `timestep + 2`).
 void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     {
     if (m_group->getNumMembersGlobal() == 0)
@@ -94,14 +94,9 @@ void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     const auto& hook = m_pdata->getDisplacementCheckHook();
     if (hook && a.one.d_group_members == nullptr && a.one.group_size == m_pdata->getN())
         {
-        if (m_block_counter.size() == 0)
-            {
-            m_block_counter.resize(1, false);
-            m_block_counter.zero();
-            }
-        if (!hook(a.check, timestep + 1))
+        // step one of timestep + 1 produces the positions of time step timestep + 2
+        if (!hook(a.check, timestep + 2))
             std::memset(&a.check, 0, sizeof(a.check));
-        a.d_block_counter = m_block_counter.get();
         }
     ScopedKernelTimer t("step_two_one");
     abiCheck(hmd_nve_step_two_one_check(&a, nullptr), "hmd_nve_step_two_one_check");

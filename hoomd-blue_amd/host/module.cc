@@ -160,12 +160,13 @@ PYBIND11_MODULE(_hoomd_amd, m)
     m.def("synchronize", []() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); });
     m.def("abi_version", []() { return hmd_abi_version(); });
 
-    m.def("enable_kernel_timing", [](bool on, const std::string& only)
+    m.def("enable_kernel_timing", [](bool on, const std::string& only, double min_us)
           {
           KernelTimer::get().setFilter(only);
+          KernelTimer::get().setMinMs(min_us * 1e-3);
           KernelTimer::get().enable(on);
           },
-          py::arg("on"), py::arg("only") = "");
+          py::arg("on"), py::arg("only") = "", py::arg("min_us") = 0.0);
     m.def("reset_kernel_timing", []() { KernelTimer::get().reset(); });
     m.def("kernel_timing", []()
           {

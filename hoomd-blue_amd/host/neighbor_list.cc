@@ -209,6 +209,10 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         ScopedKernelTimer t("nlist_check");
         abiCheck(hmd_nlist_needs_update_check(&a, nullptr), "hmd_nlist_needs_update_check");
         }
+    // only on the consumer's own path (compute): a communicator peeking at the rebuild decision has not
+    // refreshed the ghost particles yet
+    if (m_speculate && m_in_compute && !m_sysdef->isDomainDecomposed())
+        m_speculate(timestep, m_flag.get(), m_checkn);
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
     unsigned long long v = 0;
     for (uint64_t spins = 0;; spins++)
@@ -500,8 +504,12 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
         m_head_dirty = false;
         }
 
-    if (needsUpdating(timestep))
+    m_in_compute = true;
+    const bool rebuild = needsUpdating(timestep);
+    m_in_compute = false;
+    if (rebuild)
         {
+        m_last_build_tstep = timestep;
         checkBoxSize();
         m_tiles_overflowed = false;
         bool overflowed = false;

@@ -374,6 +374,8 @@ std::vector<std::tuple<std::string, uint64_t, double>> KernelTimer::collect()
         {
         float ms = 0;
         hipCheck(hipEventElapsedTime(&ms, r.e0, r.e1), "hipEventElapsedTime");
+        if (ms < m_min_ms)
+            r.name += "_skipped";
         bool found = false;
         for (auto& a : m_acc)
             if (std::get<0>(a) == r.name)

@@ -286,6 +286,13 @@ typedef struct
     unsigned int shift_mode;
     unsigned int compute_virial;
     unsigned int threads_per_particle; /* power of two in [1,64]; 0 = library default */
+    /* Optional: when d_skip_flag is not NULL and *d_skip_flag == skip_value at launch, the kernel does
+       nothing.  Lets a caller queue the launch behind the neighbor-list distance check
+       (hmd_nlist_needs_update_check: d_result / checkn) before the host has read the check's result:
+       if the list turns out stale the launch is a no-op and the caller launches again after the
+       rebuild. */
+    const unsigned int* d_skip_flag;
+    unsigned int skip_value;
     } hmd_pair_args_t;
 
 /* EvaluatorPairLJ::param_type (hoomd/md/EvaluatorPairLJ.h:99-155) */
@@ -375,14 +382,13 @@ int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
    same particles when nothing else happens between two time steps; results are bit-identical to
    calling them in that order.  `two` and `one` must name the same group.  check.d_result == NULL
    skips the check; otherwise the group must be every particle (d_group_members NULL,
-   group_size == check.N).  With check.d_published set, the last workgroup to finish publishes
-   (stamp << 32 | *d_result); d_block_counter is one zeroed word of device memory it uses. */
+   group_size == check.N).  With check.d_published set, (stamp << 32 | *d_result) is published by a
+   one-wave kernel queued behind the pass. */
 typedef struct
     {
     hmd_step_two_args_t two;
     hmd_step_one_args_t one;
     hmd_nlist_check_args_t check;
-    unsigned int* d_block_counter;
     } hmd_fused_step_args_t;
 int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, void* stream);
 
