@@ -28,11 +28,34 @@ __device__ __forceinline__ unsigned int pf_xcd_remap(unsigned int b, unsigned in
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
 
+// value of `v` in another lane through the data-parallel-primitive path of the VALU (no LDS traffic,
+// unlike __shfl*, which goes through ds_bpermute)
+template<int CTRL> __device__ __forceinline__ double pf_dpp(double v)
+    {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+    }
+
+// Sum over the TPP lanes of a particle; the result is complete in the group's first lane (all lanes for
+// TPP > 16).  quad_perm [1,0,3,2] = 0xb1, [2,3,0,1] = 0x4e, row_shl:4 = 0x104, row_shl:8 = 0x108.
 template<int TPP> __device__ __forceinline__ double pf_reduce(double v)
     {
+    if (TPP > 16)
+        {
 #pragma unroll
-    for (int m = TPP / 2; m > 0; m >>= 1)
-        v += __shfl_xor(v, m, 64);
+        for (int m = TPP / 2; m > 0; m >>= 1)
+            v += __shfl_xor(v, m, 64);
+        return v;
+        }
+    if (TPP >= 2)
+        v += pf_dpp<0xb1>(v);
+    if (TPP >= 4)
+        v += pf_dpp<0x4e>(v);
+    if (TPP >= 8)
+        v += pf_dpp<0x104>(v);
+    if (TPP >= 16)
+        v += pf_dpp<0x108>(v);
     return v;
     }
 
