@@ -151,6 +151,18 @@ def main():
     algo_bytes = 4.0 * listed + 76.0 * n_local
     achieved = algo_bytes / avg_s / 1e9 if calls else float("nan")
 
+    # HBM traffic of the pair-force kernel per launch from the L2 memory-side counters (FETCH_SIZE / WRITE_SIZE in
+    # separate rocprofv3 --pmc passes, scripts/measure_traffic.sh): counters cannot be read from inside this
+    # process, so the figure measured for this configuration is carried in profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f)
+        if tr.get("N") == n_local and world == 1:
+            traffic = tr["kernels"]["pair_force_tiles_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "particle-steps/s (whole job) of the LJ-liquid short-range MD step; timesteps/s alongside",
@@ -173,9 +185,9 @@ def main():
                 "shortest_rebuild": int(cell.shortest_rebuild), "mean_listed_neighbors": listed / max(n_local, 1),
             },
             "roofline": {
-                "kernel": "pair_force_kernel<EvaluatorPairLJ> (rank 0)",
+                "kernel": "pair_force_tiles_kernel<EvaluatorPairLJ> (rank 0)" if cell._cpp_obj.tiles_active else "pair_force_kernel<EvaluatorPairLJ> (rank 0)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
+                "traffic": traffic, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
