@@ -224,7 +224,8 @@ class DomainDecomposition:
         self.communicator.nlists.append(nlist)
 
     def _allreduce_sum_list(self, values):
-        dev = self.communicator.exchange.device if self.communicator is not None else "cpu"
+        ex = self.communicator.exchange if self.communicator is not None else None
+        dev = ex.device if ex is not None and not ex._stage else "cpu"
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.tolist()
@@ -461,6 +462,10 @@ class Communicator(_cpp.Communicator):
         self.nlists = []
         self._force_migrate = True
         self._pack_buf = None
+        self._flag_view = None
+        self._vote = None
+        self._in_communicate = False
+        self._ghosts_fresh = False
         self.exchange = ParticleExchange(decomposition, PDataArrays(self.pdata), pack_fn=self._pack_kernel)
 
     def _pack_kernel(self, ex):
@@ -494,13 +499,40 @@ class Communicator(_cpp.Communicator):
     def anyRank(self, local):
         return self.exchange.any_rank(bool(local))
 
+    def beginRebuildVote(self, d_flag, checkn):
+        """Device-side rebuild vote: no host round trip between the distance check and the reduction.
+        On the (common) steps where only ghost positions need refreshing the halo exchange is queued first,
+        so one wait covers both and work predicated on the vote can be queued behind it."""
+        ex = self.exchange
+        if self._flag_view is None or self._flag_view[0] != d_flag:
+            self._flag_view = (d_flag, torch.as_tensor(_DevMem(d_flag, (1,), "<i4"), device=ex.device))
+        if self._in_communicate and not self._force_migrate and not self._ghosts_fresh:
+            ex.update_ghosts()
+            self._ghosts_fresh = True
+        self._vote = (self._flag_view[1] == int(checkn)).to(torch.int32)
+        if ex._stage:  # gloo rehearsal on device memory: reduce through the host
+            v = self._vote.cpu()
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.dd.group)
+            self._vote.copy_(v)
+        else:
+            dist.all_reduce(self._vote, op=dist.ReduceOp.MAX, group=self.dd.group)
+        return self._vote.data_ptr()
+
+    def endRebuildVote(self):
+        return bool(self._vote.item())
+
     def communicate(self, timestep):
         ex = self.exchange
         ex.arrays.refresh()
         migrate = self._force_migrate
-        for nl in self.nlists:
-            if nl._cpp_obj is not None and nl._cpp_obj.peekUpdate(timestep):
-                migrate = True
+        self._ghosts_fresh = False
+        self._in_communicate = True
+        try:
+            for nl in self.nlists:
+                if nl._cpp_obj is not None and nl._cpp_obj.peekUpdate(timestep):
+                    migrate = True
+        finally:
+            self._in_communicate = False
         if migrate:
             self._force_migrate = False
             ex.migrate()
@@ -508,5 +540,5 @@ class Communicator(_cpp.Communicator):
             # the neighbor list must stay identical across ranks or their collective calls diverge
             self.pdata.notifyParticleSort()
             ex.exchange_ghosts(self.getGhostLayerMaxWidth())
-        else:
+        elif not self._ghosts_fresh:
             ex.update_ghosts()

@@ -501,6 +501,18 @@ class Communicator
     virtual Scalar getGhostLayerMaxWidth() const = 0;
     //! global logical OR of a local flag (the rebuild vote, hoomd/md/NeighborListGPU.cc:84-98)
     virtual bool anyRank(bool local) = 0;
+    //! The same vote without a host round trip in the middle: d_flag is the device word of the distance
+    //! check ("stale" when it equals checkn).  Queues the reduction over all ranks behind the check and
+    //! returns the address of a device word that becomes 1 when any rank is stale, 0 otherwise (0 = not
+    //! supported: fall back to anyRank).  endRebuildVote() waits for it and returns its value.
+    virtual uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn)
+        {
+        return 0;
+        }
+    virtual bool endRebuildVote()
+        {
+        return false;
+        }
     };
 
 // ---------------------------------------------------------------------------------------------

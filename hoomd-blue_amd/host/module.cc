@@ -117,6 +117,14 @@ class PyCommunicator : public Communicator
         {
         PYBIND11_OVERRIDE_PURE(bool, Communicator, anyRank, local);
         }
+    uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn) override
+        {
+        PYBIND11_OVERRIDE(uintptr_t, Communicator, beginRebuildVote, d_flag, checkn);
+        }
+    bool endRebuildVote() override
+        {
+        PYBIND11_OVERRIDE(bool, Communicator, endRebuildVote);
+        }
     };
 
 template<class Ev, class P2D, class D2P> void export_pair(py::module& m, const char* name, P2D params_to_dict, D2P dict_to_params)
@@ -227,7 +235,9 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("communicate", &Communicator::communicate)
         .def("forceMigrate", &Communicator::forceMigrate)
         .def("getGhostLayerMaxWidth", &Communicator::getGhostLayerMaxWidth)
-        .def("anyRank", &Communicator::anyRank);
+        .def("anyRank", &Communicator::anyRank)
+        .def("beginRebuildVote", &Communicator::beginRebuildVote)
+        .def("endRebuildVote", &Communicator::endRebuildVote);
 
     py::class_<SystemDefinition, std::shared_ptr<SystemDefinition>>(m, "SystemDefinition")
         .def(py::init([](py::dict snap, const BoxDim& box, unsigned int ndim, unsigned int seed, unsigned int n_global)

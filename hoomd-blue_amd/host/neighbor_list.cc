@@ -209,9 +209,22 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         ScopedKernelTimer t("nlist_check");
         abiCheck(hmd_nlist_needs_update_check(&a, nullptr), "hmd_nlist_needs_update_check");
         }
-    // only on the consumer's own path (compute): a communicator peeking at the rebuild decision has not
-    // refreshed the ghost particles yet
-    if (m_speculate && m_in_compute && !m_sysdef->isDomainDecomposed())
+    if (m_sysdef->isDomainDecomposed())
+        {
+        // the vote of all ranks is reduced on the device, queued behind the check; the communicator also
+        // refreshes the ghost positions in the same breath, so work that is valid for a fresh list can be
+        // queued behind the vote before the host has seen it
+        auto comm = m_sysdef->getCommunicator();
+        const uintptr_t d_vote = comm->beginRebuildVote((uintptr_t)m_flag.get(), m_checkn);
+        if (d_vote)
+            {
+            if (m_speculate)
+                m_speculate(timestep, reinterpret_cast<const unsigned int*>(d_vote), 1u);
+            return comm->endRebuildVote();
+            }
+        }
+    // only on the consumer's own path (compute): nothing else touches the particles before the forces
+    else if (m_speculate && m_in_compute)
         m_speculate(timestep, m_flag.get(), m_checkn);
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
     unsigned long long v = 0;
