@@ -356,10 +356,11 @@ class ParticleExchange:
         n_recv = sum(recv_counts)
         self.n_migrated_out += n_leave
         self.n_migrated_in += n_recv
-        if n_leave == 0 and n_recv == 0:
-            return False
+        # every rank takes part in the collective, also with nothing to send or receive
         incoming = torch.empty((n_recv, _ELEM), dtype=torch.int64, device=self.device)
         self._a2a(incoming, payload, recv_counts, send_counts)
+        if n_leave == 0 and n_recv == 0:
+            return False
         keep = torch.nonzero(~leave).flatten()
         n_keep = int(keep.numel())
         new_n = n_keep + n_recv

@@ -150,6 +150,23 @@ def main():
     assert np.abs(d).max() < 1e-12
     assert np.array_equal(A.pos[A.N:A.N + A.n_ghosts, 3].numpy().view(np.int64), gt % 3)
 
+    # a migration that involves two ranks only: the others still have to take part in every collective
+    tag = A.tag[:A.N].numpy().astype(np.int64)
+    x = A.pos[:A.N, :3].numpy()
+    step = np.zeros((N, 3))
+    if world >= 2 and dd.grid[0] >= 2:
+        if dd.coords == (0, 0, 0):
+            sel = tag[(x[:, 0] > dd.hi[0] - 0.3)]
+            step[sel, 0] = 0.4
+        allstep = [None] * world
+        dist.all_gather_object(allstep, step)
+        step = sum(allstep)
+        gpos = gpos + step
+        A.pos[:A.N, :3] += torch.from_numpy(step[tag])
+        ex.migrate()
+        ex.exchange_ghosts(w)
+        check_state(dd, ex, A, gpos, gvel, gimg0, L, w, "two-rank migration")
+
     # rebuild vote
     assert ex.any_rank(rank == world - 1) is True
     assert ex.any_rank(False) is False
