@@ -52,8 +52,8 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 // TILE (needs MODE 2): rows receive 16-bit candidate numbers of the 4x4x4-cell region around the home
 // cell's 2x2x2 block (tile.cuh) instead of particle indices, padded with 0xffff to a multiple of four.
 template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
-__global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
-                                                                unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow)
+__global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
+                                                                unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
@@ -318,8 +318,18 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_binned_kernel(hmd_nlist_binned
             }
 
         // ---- per-particle results ----
+        if (TILE && d_slot_meta && lane < nh && hidx >= a.N && (lane % wpc) == sub)
+            {
+            hmd_uint4 m = {hidx, 0u, 0u, 0u}; // a ghost: no row
+            d_slot_meta[hmd_idx2(a.cli, hbase + lane, cell)] = m;
+            }
         if (lane < nh && hidx < a.N && (lane % wpc) == sub)
             {
+            if (TILE && d_slot_meta)
+                {
+                hmd_uint4 m = {hidx, cnt, (unsigned int)(hhead / 4), 0u};
+                d_slot_meta[hmd_idx2(a.cli, hbase + lane, cell)] = m;
+                }
             a.d_n_neigh[hidx] = cnt;
             if (TILE)
                 for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < hnmax; k++)
@@ -509,7 +519,7 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
 
 template<bool ST, bool FB>
 int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
-                 unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr)
+                 unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr)
     {
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const dim3 grid(hmd_div_up(ncells, cells_per_block));
@@ -522,18 +532,19 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     if (d_tile)
         {
         HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
         }
     else if (fixed_images)
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
     else if (hmd_box_is_ortho(a.box))
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
     return hmd_launch_status();
     }
 
-int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow)
+int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow,
+                        hmd_uint4* d_slot_meta)
     {
     const bool single = (a.ntypes == 1);
     const bool fb = a.filter_body != 0;
@@ -546,12 +557,12 @@ int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigne
         wpc = 4;
     const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
     if (single && !fb)
-        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
     if (single && fb)
-        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
     if (!single && !fb)
-        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
-    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow);
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
     }
     } // namespace
 
@@ -578,7 +589,7 @@ extern "C" int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, voi
     if (a.N == 0)
         return HMD_OK;
 
-    return nlist_binned_driver(a, (hipStream_t)stream, nullptr, 0u, nullptr);
+    return nlist_binned_driver(a, (hipStream_t)stream, nullptr, 0u, nullptr, nullptr);
     }
 
 // Tile rows from the same kernel (declared with the tile path in the header).
@@ -621,7 +632,7 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     a.d_r_cut = t.d_r_cut;
     a.r_buff = t.r_buff;
     a.ntypes = t.ntypes;
-    return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow);
+    return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta);
     }
 
 extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream)

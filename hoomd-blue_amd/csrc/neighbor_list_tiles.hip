@@ -41,6 +41,25 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
         }
     }
 
+__global__ void __launch_bounds__(256) tile_slots_kernel(hmd_tile_geom_t g, unsigned int* d_slot_of, unsigned int nslots)
+    {
+    const unsigned int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nslots)
+        return;
+    const unsigned int cell = w / g.cli.w, k = w % g.cli.w;
+    if (k < min(g.d_cell_size[cell], g.cli.w))
+        d_slot_of[g.d_cell_idx[w]] = w;
+    }
+
+__global__ void __launch_bounds__(256) tile_refresh_kernel(const hmd_scalar4* d_pos, const unsigned int* d_slot_of, hmd_scalar4* d_cpos, unsigned int n)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double4 p = hmd_ld4(d_pos + i);
+    hmd_st4(d_cpos + d_slot_of[i], p.x, p.y, p.z, p.w);
+    }
+
 size_t build_lds_bytes(unsigned int cap, unsigned int ntypes)
     {
     size_t b = (size_t)cap * 24 + ((size_t)cap + (cap & 1)) * 4;
@@ -86,5 +105,27 @@ extern "C" int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, voi
     const size_t lds = ((size_t)a.geom.capacity * 4 + 15) / 16 * 16;
     hmd::tile_allow_big_lds(tiles_to_rows_kernel, lds);
     hipLaunchKernelGGL(tiles_to_rows_kernel, dim3(hmd::tile_num_blocks(a.geom.ci)), dim3(hmd::TL_THREADS), lds, (hipStream_t)stream, a);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_tile_slots(const hmd_tile_geom_t* geom, unsigned int* d_slot_of, void* stream)
+    {
+    HMD_REQUIRE(geom && d_slot_of && geom->d_cell_size && geom->d_cell_idx, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_tile_slots: geom (cell_size, cell_idx) and d_slot_of are required");
+    const size_t nslots = (size_t)geom->cli.w * geom->cli.h;
+    HMD_REQUIRE(nslots <= 0xffffffffull, HMD_ERR_TOO_LARGE, "hmd_tile_slots: more than 2^32 cell-list slots");
+    if (nslots == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(tile_slots_kernel, dim3(hmd_div_up((unsigned int)nslots, 256)), dim3(256), 0, (hipStream_t)stream, *geom, d_slot_of,
+                       (unsigned int)nslots);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_tile_refresh(const hmd_scalar4* d_pos, const unsigned int* d_slot_of, hmd_scalar4* d_cpos, unsigned int n, void* stream)
+    {
+    HMD_REQUIRE(d_pos && d_slot_of && d_cpos, HMD_ERR_INVALID_ARGUMENT, "hmd_tile_refresh: pos, slot_of and cpos are required");
+    if (n == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(tile_refresh_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d_pos, d_slot_of, d_cpos, n);
     return hmd_launch_status();
     }

@@ -96,97 +96,142 @@ __global__ void __launch_bounds__(PFT_THREADS)
                 }
         return lh;
     };
-    // ---- stage the region (one wave per region cell, eight cells in flight) and the home table.
-    // Loads are issued in two dependent rounds only: member indices, then positions / row info. ----
     const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    unsigned int my_h = threadIdx.x, my_idx = 0, my_lh = 0;
-    if (my_h < H)
+    if (g.d_cpos && g.d_slot_meta)
         {
-        unsigned int rc_home;
-        my_lh = home_local(my_h, rc_home);
-        my_idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (my_lh - T.off[rc_home])];
-        }
-#pragma unroll
-    for (int round = 0; round < 2; round++)
-        {
-        const unsigned int rc0 = wave * PFT_CELLS + round * PFT_BATCH;
-        unsigned int idx[PFT_BATCH];
-        bool on[PFT_BATCH];
-#pragma unroll
-        for (int q = 0; q < PFT_BATCH; q++)
+        // ---- fast staging: positions and row info are kept in cell-list slot order, so one round of
+        // loads with every lane busy fills the tile and the home table ----
+        for (unsigned int h = threadIdx.x; h < H; h += PFT_THREADS)
             {
-            const unsigned int rc = rc0 + q;
-            on[q] = rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC) && lane < T.off[rc + 1] - T.off[rc];
-            idx[q] = on[q] ? g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + lane] : 0u;
-            }
-        double4 p[PFT_BATCH];
-#pragma unroll
-        for (int q = 0; q < PFT_BATCH; q++)
-            p[q] = hmd_ld4(a.d_pos + idx[q]);
-        if (round == 0 && my_h < H)
-            {
+            unsigned int rc_home;
+            const unsigned int lh = home_local(h, rc_home);
+            const hmd_uint4 m = g.d_slot_meta[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
             pft_home_t e;
-            e.idx = my_idx;
-            e.nn = 0;
-            e.row = 0;
-            e.lh = my_lh;
-            if (my_idx < a.N)
-                {
-                e.nn = a.d_n_neigh[my_idx];
-                e.row = (unsigned int)(a.d_head_list[my_idx] / 4);
-                }
-            s_home[my_h] = e;
+            e.idx = m.x;
+            e.nn = m.y;
+            e.row = m.z;
+            e.lh = lh;
+            s_home[h] = e;
             }
-#pragma unroll
-        for (int q = 0; q < PFT_BATCH; q++)
+        for (unsigned int base = 0; base < total; base += 4 * PFT_THREADS)
             {
-            const unsigned int rc = rc0 + q;
-            if (on[q])
+            double4 p[4];
+            unsigned int rc[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
                 {
-                const unsigned int v = T.off[rc] + lane;
-                double x = p[q].x, y = p[q].y, z = p[q].z;
+                v[u] = base + u * PFT_THREADS + threadIdx.x;
+                rc[u] = v[u] < total ? tile_find_cell(T, v[u]) : 0u;
+                const unsigned int slot = v[u] < total ? (unsigned int)T.cell[rc[u]] * g.cli.w + (v[u] - T.off[rc[u]]) : 0u;
+                p[u] = hmd_ld4(g.d_cpos + slot);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (v[u] < total)
+                    {
+                    double x = p[u].x, y = p[u].y, z = p[u].z;
+                    tile_place(a.box, T, rc[u], x, y, z);
+                    txyz[3 * v[u] + 0] = x;
+                    txyz[3 * v[u] + 1] = y;
+                    txyz[3 * v[u] + 2] = z;
+                    if (!SINGLE_TYPE)
+                        ttype[v[u]] = (unsigned char)hmd_double_as_uint(p[u].w);
+                    }
+            }
+        }
+    else
+        {
+        // ---- stage the region (one wave per region cell, eight cells in flight) and the home table.
+        // Loads are issued in two dependent rounds only: member indices, then positions / row info. ----
+        unsigned int my_h = threadIdx.x, my_idx = 0, my_lh = 0;
+        if (my_h < H)
+            {
+            unsigned int rc_home;
+            my_lh = home_local(my_h, rc_home);
+            my_idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (my_lh - T.off[rc_home])];
+            }
+    #pragma unroll
+        for (int round = 0; round < 2; round++)
+            {
+            const unsigned int rc0 = wave * PFT_CELLS + round * PFT_BATCH;
+            unsigned int idx[PFT_BATCH];
+            bool on[PFT_BATCH];
+    #pragma unroll
+            for (int q = 0; q < PFT_BATCH; q++)
+                {
+                const unsigned int rc = rc0 + q;
+                on[q] = rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC) && lane < T.off[rc + 1] - T.off[rc];
+                idx[q] = on[q] ? g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + lane] : 0u;
+                }
+            double4 p[PFT_BATCH];
+    #pragma unroll
+            for (int q = 0; q < PFT_BATCH; q++)
+                p[q] = hmd_ld4(a.d_pos + idx[q]);
+            if (round == 0 && my_h < H)
+                {
+                pft_home_t e;
+                e.idx = my_idx;
+                e.nn = 0;
+                e.row = 0;
+                e.lh = my_lh;
+                if (my_idx < a.N)
+                    {
+                    e.nn = a.d_n_neigh[my_idx];
+                    e.row = (unsigned int)(a.d_head_list[my_idx] / 4);
+                    }
+                s_home[my_h] = e;
+                }
+    #pragma unroll
+            for (int q = 0; q < PFT_BATCH; q++)
+                {
+                const unsigned int rc = rc0 + q;
+                if (on[q])
+                    {
+                    const unsigned int v = T.off[rc] + lane;
+                    double x = p[q].x, y = p[q].y, z = p[q].z;
+                    tile_place(a.box, T, rc, x, y, z);
+                    txyz[3 * v + 0] = x;
+                    txyz[3 * v + 1] = y;
+                    txyz[3 * v + 2] = z;
+                    if (!SINGLE_TYPE)
+                        ttype[v] = (unsigned char)hmd_double_as_uint(p[q].w);
+                    }
+                }
+            }
+        // the uncommon leftovers: cells with more than 64 members, blocks with more than 256 home particles
+        for (unsigned int rc = wave * PFT_CELLS; rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC); rc++)
+            {
+            const unsigned int size = T.off[rc + 1] - T.off[rc];
+            for (unsigned int k = lane + 64; k < size; k += 64)
+                {
+                const unsigned int j = g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + k];
+                const double4 pp = hmd_ld4(a.d_pos + j);
+                const unsigned int v = T.off[rc] + k;
+                double x = pp.x, y = pp.y, z = pp.z;
                 tile_place(a.box, T, rc, x, y, z);
                 txyz[3 * v + 0] = x;
                 txyz[3 * v + 1] = y;
                 txyz[3 * v + 2] = z;
                 if (!SINGLE_TYPE)
-                    ttype[v] = (unsigned char)hmd_double_as_uint(p[q].w);
+                    ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
                 }
             }
-        }
-    // the uncommon leftovers: cells with more than 64 members, blocks with more than 256 home particles
-    for (unsigned int rc = wave * PFT_CELLS; rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC); rc++)
-        {
-        const unsigned int size = T.off[rc + 1] - T.off[rc];
-        for (unsigned int k = lane + 64; k < size; k += 64)
+        for (unsigned int h = threadIdx.x + PFT_THREADS; h < H; h += PFT_THREADS)
             {
-            const unsigned int j = g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + k];
-            const double4 pp = hmd_ld4(a.d_pos + j);
-            const unsigned int v = T.off[rc] + k;
-            double x = pp.x, y = pp.y, z = pp.z;
-            tile_place(a.box, T, rc, x, y, z);
-            txyz[3 * v + 0] = x;
-            txyz[3 * v + 1] = y;
-            txyz[3 * v + 2] = z;
-            if (!SINGLE_TYPE)
-                ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
+            unsigned int rc_home;
+            const unsigned int lh = home_local(h, rc_home);
+            pft_home_t e;
+            e.idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
+            e.nn = 0;
+            e.row = 0;
+            e.lh = lh;
+            if (e.idx < a.N)
+                {
+                e.nn = a.d_n_neigh[e.idx];
+                e.row = (unsigned int)(a.d_head_list[e.idx] / 4);
+                }
+            s_home[h] = e;
             }
-        }
-    for (unsigned int h = threadIdx.x + PFT_THREADS; h < H; h += PFT_THREADS)
-        {
-        unsigned int rc_home;
-        const unsigned int lh = home_local(h, rc_home);
-        pft_home_t e;
-        e.idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
-        e.nn = 0;
-        e.row = 0;
-        e.lh = lh;
-        if (e.idx < a.N)
-            {
-            e.nn = a.d_n_neigh[e.idx];
-            e.row = (unsigned int)(a.d_head_list[e.idx] / 4);
-            }
-        s_home[h] = e;
         }
     if (threadIdx.x == 0)
         {

@@ -212,6 +212,8 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
         a.geom = geom
         a.d_cell_xyzf, a.d_cell_type_body, a.d_cell_adj = ptr(cl["xyzf"]), ptr(cl["type_body"]), ptr(adj)
         a.cadji = Index2D(adj.shape[1], cl["cell_size"].numel())
+        slot_meta = torch.zeros((cl["cell_size"].numel() * cl["Nmax"], 4), dtype=torch.int32, device=dev)
+        a.d_slot_meta = ptr(slot_meta)
         a.d_tile_nlist, a.d_n_neigh, a.d_last_updated_pos, a.d_conditions = ptr(tiles), ptr(n_neigh), ptr(last_pos), ptr(cond)
         a.d_Nmax, a.d_head_list, a.d_pos, a.N, a.box = ptr(Nmax_t), ptr(head), ptr(pos), N, box
         a.d_r_cut, a.r_buff, a.ntypes, a.d_tile_overflow = ptr(r_cut_t), float(r_buff), nt, ptr(overflow)
@@ -226,8 +228,11 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
             nm[over] = np.where(c[over] > 4, (c[over] + 3) & ~3, 4)
             Nmax_t = torch.as_tensor(nm.astype(np.int32), device=dev)
             continue
+        # slot of every cell-list member, for the slot-ordered position copy of the fast staging path
+        slot_of = torch.zeros(pos.shape[0], dtype=torch.int32, device=dev)
+        check(_abi.lib.hmd_tile_slots(C.byref(geom), ptr(slot_of), _stream(pos)), "hmd_tile_slots")
         # geom points into the cell list's tensors: keep them alive with the result
-        return dict(tiles=tiles, n_neigh=n_neigh, head=head, last_pos=last_pos, Nmax=Nmax_t, n_builds=n_builds, geom=geom, args=a,
+        return dict(slot_meta=slot_meta, slot_of=slot_of, tiles=tiles, n_neigh=n_neigh, head=head, last_pos=last_pos, Nmax=Nmax_t, n_builds=n_builds, geom=geom, args=a,
                     cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow)
 
 
@@ -241,7 +246,14 @@ def tiles_to_rows(tl, N, box):
     return nlist
 
 
-def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, shift_mode=0, compute_virial=True, tpp=0, n_total=None):
+def tile_refresh(pos, tl):
+    """Slot-ordered copy of the current positions (hmd_tile_refresh)."""
+    cpos = torch.full((tl["slot_meta"].shape[0], 4), float("nan"), dtype=torch.float64, device=pos.device)
+    check(_abi.lib.hmd_tile_refresh(ptr(pos), ptr(tl["slot_of"]), ptr(cpos), pos.shape[0], _stream(pos)), "hmd_tile_refresh")
+    return cpos
+
+
+def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, shift_mode=0, compute_virial=True, tpp=0, n_total=None, fast=False):
     dev = pos.device
     n_total = pos.shape[0] if n_total is None else n_total
     prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
@@ -257,7 +269,12 @@ def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, sh
     a.d_rcutsq, a.d_ronsq, a.size_neigh_list, a.ntypes = ptr(rc), ptr(ro), tl["tiles"].numel(), nt
     a.shift_mode, a.compute_virial, a.threads_per_particle = shift_mode, int(compute_virial), tpp
     fn = {"lj": _abi.lib.hmd_compute_pair_forces_lj_tiles, "example": _abi.lib.hmd_compute_pair_forces_example_tiles}[evaluator]
-    check(fn(C.byref(a), C.byref(tl["geom"]), ptr(tl["tiles"]), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_%s_tiles" % evaluator)
+    geom = _abi.TileGeom.from_buffer_copy(tl["geom"])
+    cpos = None
+    if fast:
+        cpos = tile_refresh(pos, tl)
+        geom.d_cpos, geom.d_slot_meta = ptr(cpos), ptr(tl["slot_meta"])
+    check(fn(C.byref(a), C.byref(geom), ptr(tl["tiles"]), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_%s_tiles" % evaluator)
     return force, virial
 
 

@@ -219,6 +219,8 @@ template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d
         a.threads_per_particle = 0; // the tile kernel is built for 4, 8 and 16 lanes per particle
     a.d_skip_flag = d_skip_flag;
     a.skip_value = skip_value;
+    if (tiles)
+        m_nlist->refreshTilePositions();
     ScopedKernelTimer t("pair_force");
     if (tiles)
         {

@@ -863,6 +863,8 @@ class NeighborListGPUBinned : public Compute
         return m_tile_nlist;
         }
     hmd_tile_geom_t getTileGeom() const;
+    //! copy the current positions (owned and ghost) into cell-list slot order for the tile force kernel
+    void refreshTilePositions();
     //! Called from compute() right after a distance check has been queued and before the host waits for
     //! its result, with the device flag and the value it takes when the list is stale: a consumer may
     //! queue work that is only valid for a fresh list, predicated on the flag.
@@ -955,6 +957,9 @@ class NeighborListGPUBinned : public Compute
     bool m_tiles_enabled = true, m_tiles_active = false, m_rows_valid = true, m_tiles_overflowed = false;
     unsigned int m_tile_capacity = 0;
     DeviceArray<unsigned short> m_tile_nlist;
+    DeviceArray<unsigned int> m_slot_of;   // particle index -> cell-list slot
+    DeviceArray<Scalar4> m_cpos;           // positions in slot order, refreshed before each force launch
+    DeviceArray<hmd_uint4> m_slot_meta;    // per slot: particle index, n_neigh, row offset / 4
 
     // exclusions
     bool m_exclusions_set = false, m_ex_dirty = false;

@@ -398,10 +398,20 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         {
         if (m_tile_nlist.size() < m_nlist.size() + 256)
             m_tile_nlist.resize(m_nlist.size() + 256, false);
+        const hmd_index2d_t cli = m_cl->getCellListIndexer();
+        const size_t nslots = (size_t)cli.w * cli.h;
+        if (m_cpos.size() < nslots)
+            {
+            m_cpos.resize(nslots, false);
+            m_slot_meta.resize(nslots, false);
+            }
+        if (m_slot_of.size() < m_pdata->getMaxN())
+            m_slot_of.resize(std::max(m_pdata->getMaxN(), 1u), false);
         hmd_nlist_tiles_args_t a;
         std::memset(&a, 0, sizeof(a));
         m_tile_capacity = capacity;
         a.geom = getTileGeom();
+        a.d_slot_meta = m_slot_meta.get();
         a.d_cell_xyzf = m_cl->getXYZFArray().get();
         a.d_cell_type_body = m_cl->getTypeBodyArray().get();
         a.d_cell_adj = m_cl->getCellAdjArray().get();
@@ -421,6 +431,7 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         a.d_tile_overflow = m_conditions.get() + a.ntypes;
         hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
         abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
+        abiCheck(hmd_tile_slots(&a.geom, m_slot_of.get(), nullptr), "hmd_tile_slots");
         m_tiles_active = true;
         m_rows_valid = false;
         return;
@@ -463,7 +474,15 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
     g.ci = m_cl->getCellIndexer();
     g.cli = m_cl->getCellListIndexer();
     g.capacity = m_tile_capacity;
+    g.d_cpos = m_cpos.get();
+    g.d_slot_meta = m_slot_meta.get();
     return g;
+    }
+
+void NeighborListGPUBinned::refreshTilePositions()
+    {
+    ScopedKernelTimer t("tile_refresh");
+    abiCheck(hmd_tile_refresh(m_pdata->pos(), m_slot_of.get(), m_cpos.get(), m_pdata->getN() + m_pdata->getNGhosts(), nullptr), "hmd_tile_refresh");
     }
 
 // can this build write tile rows?  (no row filters, 3D, grid and occupancy within the tile limits)

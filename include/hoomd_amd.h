@@ -54,6 +54,10 @@ typedef struct
     {
     unsigned int x, y, z;
     } hmd_uint3;
+typedef struct
+    {
+    unsigned int x, y, z, w;
+    } hmd_uint4;
 
 /* BoxDim (hoomd/BoxDim.h:633-641) as plain data.  nearest_plane holds
    BoxDim::getNearestPlaneDistance() (hoomd/BoxDim.h:536-552) evaluated once on the host so that
@@ -503,7 +507,20 @@ typedef struct
     hmd_index3d_t ci;
     hmd_index2d_t cli;
     unsigned int capacity;           /* candidates per region the LDS tile may hold */
+    /* Optional, both or neither (the pair-force kernel then stages a region with one round of
+       coalesced loads instead of two dependent gathers):
+       d_cpos[cli(slot, cell)]      position (w = type word) of the member in that slot, refreshed by
+                                    hmd_tile_refresh before every force launch;
+       d_slot_meta[cli(slot, cell)] x = particle index, y = n_neigh, z = row offset / 4, w unused;
+                                    written by hmd_compute_nlist_tiles. */
+    const hmd_scalar4* d_cpos;
+    const hmd_uint4* d_slot_meta;
     } hmd_tile_geom_t;
+
+/* d_slot_of[particle index] = cli(slot, cell) for every member of the cell list (owned and ghost). */
+int hmd_tile_slots(const hmd_tile_geom_t* geom, unsigned int* d_slot_of, void* stream);
+/* d_cpos[d_slot_of[i]] = d_pos[i] for i < n (n = owned + ghost particles). */
+int hmd_tile_refresh(const hmd_scalar4* d_pos, const unsigned int* d_slot_of, hmd_scalar4* d_cpos, unsigned int n, void* stream);
 
 /* Returns HMD_OK and the LDS capacity to use when the tile path can serve this cell grid, else
    HMD_ERR_UNSUPPORTED (use the row-based entry points).  cell_Nmax: slots per cell (cli.w). */
@@ -518,6 +535,7 @@ typedef struct
     const unsigned int* d_cell_adj;       /* 27-cell stencil */
     hmd_index2d_t cadji;
     unsigned short* d_tile_nlist;
+    hmd_uint4* d_slot_meta;          /* optional output, see hmd_tile_geom_t */
     unsigned int* d_n_neigh;
     hmd_scalar4* d_last_updated_pos;
     unsigned int* d_conditions;      /* per type: largest row length seen (atomicMax), as the row-based build */

@@ -65,7 +65,13 @@ def variant(code):
         A.check(fn(C.byref(a), C.byref(tl["geom"]), KK.ptr(tl["tiles"]), KK.ptr(prm_t), None))
         a.block_size = 0
     return f
-print("tile force (no wrapper) us", timeit(full_only, 10), " staging only", timeit(variant(999), 10), " no-conflict LDS", timeit(variant(998), 10), " no math", timeit(variant(997), 10), " no LDS reads", timeit(variant(996), 10), " no chunks", timeit(variant(995), 10))
+cpos = K.tile_refresh(pos_t, tl)
+print("refresh us", timeit(lambda: A.check(A.lib.hmd_tile_refresh(KK.ptr(pos_t), KK.ptr(tl["slot_of"]), KK.ptr(cpos), N, None)), 10))
+gfast = A.TileGeom.from_buffer_copy(tl["geom"]); gfast.d_cpos = KK.ptr(cpos); gfast.d_slot_meta = KK.ptr(tl["slot_meta"])
+def fast_only():
+    A.check(fn(C.byref(tl["_pa"]), C.byref(gfast), KK.ptr(tl["tiles"]), KK.ptr(prm_t), None))
+print("tile force FAST staging us", timeit(fast_only, 10))
+print("tile force (no wrapper) us", timeit(full_only, 10))
 print("row force us", timeit(lambda: K.pair_forces("lj", pos_t, N, gbox, nl["n_neigh"], nl["nlist"], nl["head"], P, [[6.25]], compute_virial=False)))
 F1, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=False)
 F2, _ = K.pair_forces("lj", pos_t, N, gbox, nl["n_neigh"], nl["nlist"], nl["head"], P, [[6.25]], compute_virial=False)

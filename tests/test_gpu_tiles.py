@@ -87,8 +87,9 @@ def test_tile_ghost_layer_non_periodic_box(K, A):
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
     F_ref, _ = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(1.5, 2.0)], [[4.0]],
                                third_law=False, compute_virial=False)
-    F, _ = K.pair_forces_tiles("example", pos_t, N, gbox, tl, [(1.5, 2.0)], [[4.0]], compute_virial=False)
-    assert _rel_err(F.cpu().numpy()[:N], F_ref[:N]) < F_RTOL * 1e-4
+    for fast in (False, True):
+        F, _ = K.pair_forces_tiles("example", pos_t, N, gbox, tl, [(1.5, 2.0)], [[4.0]], compute_virial=False, fast=fast)
+        assert _rel_err(F.cpu().numpy()[:N], F_ref[:N]) < F_RTOL * 1e-4
 
 
 @pytest.mark.parametrize("shift_mode", [0, 1, 2])
@@ -110,8 +111,8 @@ def test_tile_lj_forces_match_oracle(K, A, shift_mode, ntypes):
     half = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=False)
     F_ref, V_ref = orc.pair_forces(orc.EV_LJ, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], params, rcutsq,
                                    ronsq, shift_mode=shift_mode, third_law=True, compute_virial=True)
-    for tpp in (4, 8, 16):
-        F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, ronsq, shift_mode=shift_mode, compute_virial=True, tpp=tpp)
+    for tpp, fast in ((4, False), (8, False), (16, False), (8, True), (4, True)):
+        F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, ronsq, shift_mode=shift_mode, compute_virial=True, tpp=tpp, fast=fast)
         assert _rel_err(F.cpu().numpy()[:, :3], F_ref[:, :3]) < F_RTOL * 1e-4
         assert _rel_err(F.cpu().numpy()[:, 3], F_ref[:, 3]) < F_RTOL * 1e-4
         assert _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
@@ -153,6 +154,7 @@ def test_tile_forces_after_particles_wrap_between_builds(K, A):
     pos2_t = torch.from_numpy(orc.pack_pos(wrapped, typ)).cuda()
     P = [orc.lj_params(1.0, 1.0)]
     F_rows, V_rows = K.pair_forces("lj", pos2_t, N, gbox, tl["n_neigh"], nlist, tl["head"], P, [[6.25]], compute_virial=True)
-    F_tile, V_tile = K.pair_forces_tiles("lj", pos2_t, N, gbox, tl, P, [[6.25]], compute_virial=True)
-    assert _rel_err(F_tile.cpu().numpy(), F_rows.cpu().numpy()) < F_RTOL * 1e-4
-    assert _rel_err(V_tile.cpu().numpy(), V_rows.cpu().numpy()) < F_RTOL * 1e-4
+    for fast in (False, True):
+        F_tile, V_tile = K.pair_forces_tiles("lj", pos2_t, N, gbox, tl, P, [[6.25]], compute_virial=True, fast=fast)
+        assert _rel_err(F_tile.cpu().numpy(), F_rows.cpu().numpy()) < F_RTOL * 1e-4
+        assert _rel_err(V_tile.cpu().numpy(), V_rows.cpu().numpy()) < F_RTOL * 1e-4
