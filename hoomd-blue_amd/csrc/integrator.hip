@@ -116,6 +116,8 @@ template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_st
         hmd_st4(a.one.d_pos + idx, x, y, z, p.w);
         hmd_st4(a.one.d_vel + idx, vx, vy, vz, v.w);
         a.one.d_image[idx] = img;
+        if (a.d_cpos)
+            hmd_st4(a.d_cpos + a.d_slot_of[idx], x, y, z, p.w);
         // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
         if (CHECK)
             {
@@ -303,6 +305,8 @@ extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, voi
     HMD_REQUIRE(a.two.d_vel == a.one.d_vel && a.two.d_accel == a.one.d_accel && a.two.d_group_members == a.one.d_group_members
                     && a.two.group_size == a.one.group_size,
                 HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: both halves must act on the same arrays and group");
+    HMD_REQUIRE((a.d_cpos == nullptr) == (a.d_slot_of == nullptr), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nve_step_two_one_check: d_cpos and d_slot_of go together");
     HMD_REQUIRE(!a.one.use_limit, HMD_ERR_UNSUPPORTED, "hmd_nve_step_two_one_check: the displacement limit needs the separate step-one driver");
     const bool check = a.check.d_result != nullptr;
     if (check)

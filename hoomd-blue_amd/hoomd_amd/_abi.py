@@ -153,7 +153,7 @@ class PackPosArgs(C.Structure):
 
 
 class FusedStepArgs(C.Structure):
-    _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs)]
+    _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs), ("d_slot_of", vp), ("d_cpos", vp)]
 
 
 class TileGeom(C.Structure):

@@ -334,9 +334,10 @@ class ParticleData
         {
         return m_maxn;
         }
-    //! A neighbor list may ask whoever moves the particles to run its distance check in the same pass:
-    //! the hook fills the check's arguments for the positions of `timestep` and returns false to decline.
-    typedef std::function<bool(hmd_nlist_check_args_t&, uint64_t)> DisplacementCheckHook;
+    //! A neighbor list may ask whoever moves the particles to do two things in the same pass: run its
+    //! distance check on the positions of `timestep` and mirror them into its slot-ordered copy.  The
+    //! hook fills the corresponding fields of the pass's arguments (or leaves them zero).
+    typedef std::function<void(hmd_fused_step_args_t&, uint64_t)> DisplacementCheckHook;
     void setDisplacementCheckHook(DisplacementCheckHook h)
         {
         m_check_hook = h;
@@ -865,6 +866,7 @@ class NeighborListGPUBinned : public Compute
     hmd_tile_geom_t getTileGeom() const;
     //! copy the current positions (owned and ghost) into cell-list slot order for the tile force kernel
     void refreshTilePositions();
+    void offerFusedPass(hmd_fused_step_args_t& a, uint64_t timestep);
     //! Called from compute() right after a distance check has been queued and before the host waits for
     //! its result, with the device flag and the value it takes when the list is stale: a consumer may
     //! queue work that is only valid for a fresh list, predicated on the flag.
@@ -941,6 +943,9 @@ class NeighborListGPUBinned : public Compute
     unsigned int m_checkn = 1;
     //! time step whose distance check was already launched by the integrator's fused pass
     uint64_t m_prelaunched_tstep = ~0ull;
+    //! time step for which the owned part of the slot-ordered position copy is already current
+    uint64_t m_cpos_tstep = ~0ull;
+    uint64_t m_compute_tstep = 0;
     SpeculationHook m_speculate;
     bool m_in_compute = false;
     uint64_t m_last_build_tstep = ~0ull;

@@ -95,8 +95,7 @@ void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     if (hook && a.one.d_group_members == nullptr && a.one.group_size == m_pdata->getN())
         {
         // step one of timestep + 1 produces the positions of time step timestep + 2
-        if (!hook(a.check, timestep + 2))
-            std::memset(&a.check, 0, sizeof(a.check));
+        hook(a, timestep + 2);
         }
     ScopedKernelTimer t("step_two_one");
     abiCheck(hmd_nve_step_two_one_check(&a, nullptr), "hmd_nve_step_two_one_check");

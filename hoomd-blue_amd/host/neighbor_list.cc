@@ -38,7 +38,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
     m_cl->setComputeIdx(true); // the tile kernels number candidates through the index array
     m_cl->setFlagIndex();
 
-    m_pdata->setDisplacementCheckHook([this](hmd_nlist_check_args_t& a, uint64_t timestep) { return offerCheck(a, timestep); });
+    m_pdata->setDisplacementCheckHook([this](hmd_fused_step_args_t& a, uint64_t timestep) { offerFusedPass(a, timestep); });
     m_sort_slot = m_pdata->getParticleSortSignal().connect([this]() { forceUpdate(); });
     m_box_slot = m_pdata->getBoxChangeSignal().connect([this]() { forceUpdate(); });
     m_maxn_slot = m_pdata->getMaxParticleNumberChangeSignal().connect([this]()
@@ -197,6 +197,19 @@ bool NeighborListGPUBinned::offerCheck(hmd_nlist_check_args_t& a, uint64_t times
     return true;
     }
 
+void NeighborListGPUBinned::offerFusedPass(hmd_fused_step_args_t& a, uint64_t timestep)
+    {
+    if (!offerCheck(a.check, timestep))
+        std::memset(&a.check, 0, sizeof(a.check));
+    // valid as long as the list is not rebuilt at `timestep` (a rebuild renumbers the slots and refreshes all)
+    if (m_tiles_active && !m_force_update && m_has_been_updated_once && m_slot_of.size() >= m_pdata->getN())
+        {
+        a.d_slot_of = m_slot_of.get();
+        a.d_cpos = m_cpos.get();
+        m_cpos_tstep = timestep;
+        }
+    }
+
 // hoomd/md/NeighborListGPU.cc:29-101
 bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
     {
@@ -251,6 +264,7 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
 // hoomd/md/NeighborList.cc:1325-1418
 bool NeighborListGPUBinned::needsUpdating(uint64_t timestep)
     {
+    m_compute_tstep = timestep;
     if (m_last_checked_tstep == timestep)
         {
         if (m_force_update)
@@ -481,8 +495,13 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
 
 void NeighborListGPUBinned::refreshTilePositions()
     {
+    const unsigned int N = m_pdata->getN(), ng = m_pdata->getNGhosts();
+    // the integration pass may already have mirrored the owned particles of this time step
+    const unsigned int first = (m_cpos_tstep == m_compute_tstep) ? N : 0u;
+    if (first == N && ng == 0)
+        return;
     ScopedKernelTimer t("tile_refresh");
-    abiCheck(hmd_tile_refresh(m_pdata->pos(), m_slot_of.get(), m_cpos.get(), m_pdata->getN() + m_pdata->getNGhosts(), nullptr), "hmd_tile_refresh");
+    abiCheck(hmd_tile_refresh(m_pdata->pos() + first, m_slot_of.get() + first, m_cpos.get(), N + ng - first, nullptr), "hmd_tile_refresh");
     }
 
 // can this build write tile rows?  (no row filters, 3D, grid and occupancy within the tile limits)
@@ -536,12 +555,14 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
         m_head_dirty = false;
         }
 
+    m_compute_tstep = timestep;
     m_in_compute = true;
     const bool rebuild = needsUpdating(timestep);
     m_in_compute = false;
     if (rebuild)
         {
         m_last_build_tstep = timestep;
+        m_cpos_tstep = ~0ull; // the slots are renumbered: refresh everything
         checkBoxSize();
         m_tiles_overflowed = false;
         bool overflowed = false;

@@ -387,12 +387,15 @@ int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
    calling them in that order.  `two` and `one` must name the same group.  check.d_result == NULL
    skips the check; otherwise the group must be every particle (d_group_members NULL,
    group_size == check.N).  With check.d_published set, (stamp << 32 | *d_result) is published by a
-   one-wave kernel queued behind the pass. */
+   one-wave kernel queued behind the pass.  With d_cpos / d_slot_of set, the new position of particle i
+   is also stored at d_cpos[d_slot_of[i]] (what hmd_tile_refresh would do afterwards). */
 typedef struct
     {
     hmd_step_two_args_t two;
     hmd_step_one_args_t one;
     hmd_nlist_check_args_t check;
+    const unsigned int* d_slot_of;
+    hmd_scalar4* d_cpos;
     } hmd_fused_step_args_t;
 int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, void* stream);
 
