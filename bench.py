@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpp", type=int, default=0)
+    ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka"],
+                    help="lj: the headline LJ liquid; ka: Kob-Andersen 80:20 mixture at rho 1.2 under a Bussi thermostat (side measurement)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
 
@@ -103,8 +105,12 @@ def main():
 
     per_gpu = tuple(int(x) for x in args.lattice.split("x"))
     n = tuple(a * g for a, g in zip(per_gpu, grid))
-    thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
-    sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
+    if args.workload == "ka":
+        thermostat = hoomd.md.methods.thermostats.Bussi(kT=1.0)
+        sim, cell, lj, method = lj_liquid.make_ka_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
+    else:
+        thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
+        sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
     N_total = sim.state.N_particles
     if args.tpp:
         sim.run(0)
@@ -119,7 +125,8 @@ def main():
     # ---- warm-up: melt under the thermostat (all but the last 200 steps), then NVE ----
     melt = max(args.warmup - 200, 0) if args.warmup >= 400 else args.warmup // 2
     sim.run(melt)
-    method.thermostat = None
+    if args.workload == "lj":
+        method.thermostat = None  # the Kob-Andersen case keeps its thermostat, as the reference configuration does
     sim.run(args.warmup - melt)
 
     # ---- timed region ----
@@ -179,8 +186,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
-                            "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64",
+                "workload": (f"Kob-Andersen 80:20 LJ mixture N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) "
+                             "rho=1.2 kT=1.0 r_cut=2.5 sigma_ij buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume with Bussi thermostat, fp64"
+                             if args.workload == "ka" else
+                             f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
+                             "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
                 "N": N_total, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
                 "shortest_rebuild": int(cell.shortest_rebuild), "mean_listed_neighbors": listed / max(n_local, 1),
             },

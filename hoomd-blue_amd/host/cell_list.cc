@@ -169,7 +169,7 @@ bool CellListGPU::checkConditions()
     bool result = false;
     if (h[0] > m_Nmax)
         {
-        m_Nmax = h[0];
+        m_Nmax = h[0] + m_nmax_headroom;
         result = true;
         }
     if (h[1])

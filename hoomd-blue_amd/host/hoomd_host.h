@@ -603,6 +603,12 @@ class CellListGPU : public Compute
             m_params_changed = true;
         m_radius = r;
         }
+    //! extra slots per cell allocated beyond the largest occupancy seen: a cell list that is rebuilt rarely
+    //! on a drifting system (the particle sorter's) would otherwise reallocate at almost every use
+    void setNmaxHeadroom(unsigned int h)
+        {
+        m_nmax_headroom = h;
+        }
     //! consumers that never walk neighboring cells (the particle sorter) skip the adjacency table
     void setComputeAdj(bool b)
         {
@@ -703,7 +709,7 @@ class CellListGPU : public Compute
     bool checkConditions();
 
     Scalar m_nominal_width = 0;
-    unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0;
+    unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0, m_nmax_headroom = 0;
     std::array<unsigned int, 3> m_dim {{0, 0, 0}};
     Scalar3 m_ghost_width {0, 0, 0};
     bool m_params_changed = true, m_particles_sorted = false, m_box_changed = false, m_compute_adj = true;

@@ -287,6 +287,7 @@ ParticleSorter::ParticleSorter(std::shared_ptr<SystemDefinition> sysdef, uint64_
     m_cl->setRadius(1);
     m_cl->setFlagIndex();
     m_cl->setComputeAdj(false);
+    m_cl->setNmaxHeadroom(4);
     }
 
 void ParticleSorter::update(uint64_t timestep)

@@ -46,3 +46,26 @@ def make_simulation(hoomd, n, rho=0.84, kT=1.5, r_cut=2.5, buffer=0.4, dt=0.005,
     sim.operations.integrator = hoomd.md.Integrator(dt=dt, methods=[method], forces=[lj])
     sim.operations.tuners[0].trigger = sorter_period
     return sim, cell, lj, method
+
+
+def make_ka_simulation(hoomd, n, rho=1.2, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200, decomposition=None):
+    """Kob-Andersen 80:20 binary LJ mixture: types by rng.random(N) < 0.8, eps AA/AB/BB = 1/1.5/0.5,
+    sigma = 1/0.8/0.88, r_cut = 2.5 sigma_ij."""
+    snap = make_snapshot(hoomd, n, rho, kT, seed)
+    N = snap.particles.N
+    snap.particles.types = ["A", "B"]
+    snap.particles.typeid[:] = (np.random.default_rng(seed + 1).random(N) >= 0.8).astype(np.uint32)
+    sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=seed)
+    if decomposition is not None:
+        sim.create_state_from_snapshot(snap, domain_decomposition=decomposition)
+    else:
+        sim.create_state_from_snapshot(snap)
+    cell = hoomd.md.nlist.Cell(buffer=buffer)
+    lj = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.5)
+    for pair, eps, sig in ((("A", "A"), 1.0, 1.0), (("A", "B"), 1.5, 0.8), (("B", "B"), 0.5, 0.88)):
+        lj.params[pair] = dict(epsilon=eps, sigma=sig)
+        lj.r_cut[pair] = 2.5 * sig
+    method = hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All(), thermostat=thermostat)
+    sim.operations.integrator = hoomd.md.Integrator(dt=dt, methods=[method], forces=[lj])
+    sim.operations.tuners[0].trigger = sorter_period
+    return sim, cell, lj, method
