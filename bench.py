@@ -192,7 +192,7 @@ def main():
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
                              "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
                 "N": N_total, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
-                "shortest_rebuild": int(cell.shortest_rebuild), "mean_listed_neighbors": listed / max(n_local, 1),
+                "shortest_rebuild": int(cell.shortest_rebuild), "tile_capacity": int(cell._cpp_obj.tile_capacity), "mean_listed_neighbors": listed / max(n_local, 1),
             },
             "roofline": {
                 "kernel": "pair_force_tiles_kernel<EvaluatorPairLJ> (rank 0)" if cell._cpp_obj.tiles_active else "pair_force_kernel<EvaluatorPairLJ> (rank 0)",

@@ -70,8 +70,10 @@ class EvaluatorPairLJ
     // lj1 = lj2 = 0 and zero results as well.
     __device__ __forceinline__ void evalUnshiftedBranchFree(double& force_divr, double& pair_eng) const
         {
-        const double x = (rsq < rcutsq) ? rsq : 1e300;
-        const double r2inv = fast_rcp(x);
+        // outside the cutoff rsq becomes about 1e300 and every term below underflows to zero; only the
+        // high word needs replacing for that
+        const int hi = (rsq < rcutsq) ? __double2hiint(rsq) : 0x7e37e43c;
+        const double r2inv = fast_rcp(__hiloint2double(hi, __double2loint(rsq)));
         const double r6inv = r2inv * r2inv * r2inv;
         force_divr = r2inv * r6inv * (12.0 * lj1 * r6inv - 6.0 * lj2);
         pair_eng = r6inv * (lj1 * r6inv - lj2);

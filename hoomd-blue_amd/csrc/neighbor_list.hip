@@ -49,8 +49,9 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 // of every adjacent cell is fixed up front (possible when each periodic direction has at least three
 // cells: the 3x3x3 stencil then never holds two images of one cell), so candidates are shifted once
 // when they are loaded and no minimum-image arithmetic (hoomd/BoxDim.h:306-325) runs per pair.
-// TILE (needs MODE 2): rows receive 16-bit candidate numbers of the 4x4x4-cell region around the home
-// cell's 2x2x2 block (tile.cuh) instead of particle indices, padded with 0xffff to a multiple of four.
+// TILE (needs MODE 2): rows receive 16-bit tile slots (tile_slot() of the candidate number in the 4x4x4-cell
+// region around the home cell's 2x2x2 block, tile.cuh) instead of particle indices, padded to a multiple
+// of four with the slot after the region's last candidate, where consumers keep a dummy far away.
 template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
 __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
                                                                 unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta)
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         s_shift[3 * lane + 1] = sy;
         s_shift[3 * lane + 2] = sz;
         }
+    unsigned int tile_pad = 0; // what pads a tile row: the slot of the consumers' dummy candidate
     if (TILE)
         {
         const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
@@ -164,6 +166,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             }
         if (lane == 0 && sub == 0 && rtotal > d_tile_overflow[1])
             atomicMax(d_tile_overflow + 1, rtotal);
+        tile_pad = hmd::tile_slot(rtotal);
         // region cell of each adjacent cell: home position in the block + unwrapped offset + 1
         unsigned int rc = 0;
         if (lane < n_adj)
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                             }
                         cj[c] = hmd_double_as_uint(v.w);
                         if (TILE)
-                            cl[c] = s_tileoff[lo] + (k - s_excl[lo]);
+                            cl[c] = hmd::tile_slot(s_tileoff[lo] + (k - s_excl[lo]));
                         if (!SINGLE_TYPE || FILTER_BODY)
                             {
                             const uint2 tb = *reinterpret_cast<const uint2*>(a.d_cell_type_body + w);
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             a.d_n_neigh[hidx] = cnt;
             if (TILE)
                 for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < hnmax; k++)
-                    (d_tile + hhead)[k] = 0xffffu;
+                    (d_tile + hhead)[k] = (unsigned short)tile_pad;
             if (a.d_last_updated_pos)
                 {
                 // same bits as pos[hidx]: the cell list holds a copy of x,y,z and of the type id

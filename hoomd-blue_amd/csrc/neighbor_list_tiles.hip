@@ -4,6 +4,7 @@
 // neighbor_list.hip.
 #pragma clang fp contract(off)
 #include "tile.cuh"
+#include <algorithm>
 
 namespace
     {
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
             const unsigned int n = a.d_n_neigh[i];
             const size_t head = a.d_head_list[i];
             for (unsigned int k = lane; k < n; k += 64)
-                a.d_nlist[head + k] = tidx[a.d_tile_nlist[head + k]];
+                a.d_nlist[head + k] = tidx[tile_unslot(a.d_tile_nlist[head + k])];
             }
         }
     }
@@ -82,7 +83,7 @@ extern "C" int hmd_nlist_tiles_supported(const hmd_index3d_t* ci, const hmd_box_
         }
     HMD_REQUIRE(ntypes >= 1 && ntypes <= 256, HMD_ERR_UNSUPPORTED, "tile path stores type ids in one byte");
     const size_t cap = (size_t)hmd::TL_RC * cell_Nmax;
-    HMD_REQUIRE(cap >= 1 && cap <= 65535 && build_lds_bytes((unsigned int)cap, ntypes) <= hmd::TL_MAX_LDS, HMD_ERR_UNSUPPORTED,
+    HMD_REQUIRE(cap >= 1 && hmd::tile_doubles((unsigned int)std::min<size_t>(cap, 1u << 20)) <= 65536 && build_lds_bytes((unsigned int)cap, ntypes) <= hmd::TL_MAX_LDS, HMD_ERR_UNSUPPORTED,
                 "tile path: 64 cells of this occupancy do not fit the LDS tile");
     *capacity_out = (unsigned int)cap;
     return HMD_OK;

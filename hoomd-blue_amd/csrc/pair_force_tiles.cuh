@@ -4,6 +4,8 @@
 // neighbor rows hold 16-bit candidate numbers of the workgroup's region (tile.cuh), so a neighbor's
 // coordinates are three LDS reads and the periodic image is already applied.  TPP lanes share a
 // home particle; each lane takes four consecutive row entries (one 8-byte load) per trip.
+// Row entries are tile slots (tile_slot() in tile.cuh): 8 * entry is the byte offset of x in the tile,
+// y and z follow 256 and 512 bytes later.
 #ifndef HMD_PAIR_FORCE_TILES_CUH
 #define HMD_PAIR_FORCE_TILES_CUH
 
@@ -15,12 +17,32 @@ namespace hmd
 // per home particle, kept in LDS so that no wave waits on a chain of dependent global loads
 struct pft_home_t
     {
-    unsigned int idx, nn;
-    unsigned int row; // offset of the particle's row in d_tile_nlist, in units of four entries
-    unsigned int lh;  // candidate number of the particle itself
+    unsigned int idx;
+    unsigned int row;   // offset of the particle's row in d_tile_nlist, in units of four entries
+    unsigned int nn_lh; // low half: number of neighbors; high half: tile slot of the particle itself
     };
+static_assert(sizeof(pft_home_t) == 12, "LDS budget");
+__device__ __forceinline__ pft_home_t pft_home(unsigned int idx, unsigned int nn, unsigned int row, unsigned int lh)
+    {
+    pft_home_t e = {idx, row, min(nn, 0xffffu) | (lh << 16)};
+    return e;
+    }
+
+typedef __attribute__((address_space(3))) const double pft_lds_double;
+
+// byte offset 8 * (16-bit half of w) in one instruction
+template<int HALF> __device__ __forceinline__ unsigned int pft_slot_bytes(unsigned int w, unsigned int three)
+    {
+    unsigned int r;
+    if (HALF == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(three), "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+    }
 
 constexpr int PFT_THREADS = 256;              // 4 waves share one staged region
+constexpr size_t PFT_TABLES = (sizeof(tile_tables) + 16 + 15) / 16 * 16; // tile_tables and the shared home counter
 constexpr int PFT_WAVES = PFT_THREADS / 64;
 constexpr int PFT_CELLS = (TL_RC + PFT_WAVES - 1) / PFT_WAVES; // region cells staged by one wave
 constexpr int PFT_BATCH = (PFT_CELLS + 1) / 2;                  // ... in two rounds of this many loads in flight
@@ -32,15 +54,22 @@ __global__ void __launch_bounds__(PFT_THREADS)
     typedef typename Ev::param_type param_t;
     if (a.d_skip_flag && *a.d_skip_flag == a.skip_value)
         return;
-    __shared__ tile_tables T;
-    __shared__ unsigned int s_next;
+    // All LDS of this kernel is dynamic and the tile comes first, so that the tile starts at LDS
+    // address 0 and 8 * (row entry) is the address of a neighbor's x without adding a base.
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const unsigned int cap = g.capacity;
-    // candidate c sits at txyz[3c .. 3c+2]; slot `total` is a dummy far away that padding entries point to
+    // candidate c sits at txyz[s], txyz[s + 32], txyz[s + 64], s = tile_slot(c); candidate `total` is a dummy
+    // far away that the padding of the rows points to
     double* txyz = reinterpret_cast<double*>(s_dyn);
-    pft_home_t* s_home = reinterpret_cast<pft_home_t*>(txyz + 3 * ((size_t)cap + 1));
+    const unsigned int tile_len = tile_doubles(cap);
+    tile_tables& T = *reinterpret_cast<tile_tables*>(txyz + tile_len);
+    // s_home: one entry per home particle and an empty one after the last
+    unsigned int& s_next = *reinterpret_cast<unsigned int*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES - 16);
+    pft_home_t* s_home = reinterpret_cast<pft_home_t*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES);
+    if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
+        __builtin_trap(); // the toolchain placed something before the dynamic LDS
     const unsigned int np = a.ntypes * a.ntypes;
-    double* s_rcutsq = reinterpret_cast<double*>(s_home + TL_NH * g.cli.w);
+    double* s_rcutsq = reinterpret_cast<double*>(s_home + TL_NH * g.cli.w + 1);
     double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
     unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
@@ -64,7 +93,7 @@ __global__ void __launch_bounds__(PFT_THREADS)
             s_ronsq[t] = (SHIFT == 2) ? a.d_ronsq[t] : 0.0;
             }
     if (threadIdx.x == 0)
-        s_next = PFT_THREADS / TPP;
+        s_next = 2 * (PFT_THREADS / TPP);
     __syncthreads();
     const unsigned int total = T.off[64];
     if (total > cap || total == 0)
@@ -106,37 +135,53 @@ __global__ void __launch_bounds__(PFT_THREADS)
             unsigned int rc_home;
             const unsigned int lh = home_local(h, rc_home);
             const hmd_uint4 m = g.d_slot_meta[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
-            pft_home_t e;
-            e.idx = m.x;
-            e.nn = m.y;
-            e.row = m.z;
-            e.lh = lh;
-            s_home[h] = e;
+            s_home[h] = pft_home(m.x, m.y, m.z, tile_slot(lh));
             }
-        for (unsigned int base = 0; base < total; base += 4 * PFT_THREADS)
+        // Sixteen lanes take one region cell, so a wave covers four cells per trip and the whole
+        // region in PFT_TRIPS trips, all of whose loads are in flight together.
+        constexpr int PFT_TRIPS = (TL_RC + 4 * PFT_WAVES - 1) / (4 * PFT_WAVES);
+        const double reach_sq = tile_reach_sq(a.box);
+        const unsigned int k16 = lane % 16;
+        double4 p[PFT_TRIPS];
+        unsigned int rcs[PFT_TRIPS], size[PFT_TRIPS];
+#pragma unroll
+        for (int u = 0; u < PFT_TRIPS; u++)
             {
-            double4 p[4];
-            unsigned int rc[4], v[4];
+            rcs[u] = (u * PFT_WAVES + wave) * 4 + lane / 16;
+            size[u] = rcs[u] < (unsigned int)TL_RC ? T.off[rcs[u] + 1] - T.off[rcs[u]] : 0u;
+            rcs[u] = min(rcs[u], (unsigned int)TL_RC - 1);
+            const unsigned int slot = size[u] ? (unsigned int)T.cell[rcs[u]] * g.cli.w + min(k16, size[u] - 1) : 0u;
+            p[u] = hmd_ld4(g.d_cpos + slot);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+        for (int u = 0; u < PFT_TRIPS; u++)
+            {
+            const unsigned int rc = rcs[u];
+            const tile_cell_image ci = tile_cell_setup(a.box, T, rc);
+            const unsigned int first = T.off[rc];
+            const hmd_scalar4* cell_pos = g.d_cpos + (size[u] ? (unsigned int)T.cell[rc] * g.cli.w : 0u);
+            double4 pp = p[u];
+            for (unsigned int k = k16; k < size[u]; k += 16)
                 {
-                v[u] = base + u * PFT_THREADS + threadIdx.x;
-                rc[u] = v[u] < total ? tile_find_cell(T, v[u]) : 0u;
-                const unsigned int slot = v[u] < total ? (unsigned int)T.cell[rc[u]] * g.cli.w + (v[u] - T.off[rc[u]]) : 0u;
-                p[u] = hmd_ld4(g.d_cpos + slot);
-                }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (v[u] < total)
+                if (k >= 16)
+                    pp = hmd_ld4(cell_pos + k);
+                double x = pp.x, y = pp.y, z = pp.z;
+                const double dx = x - ci.qx, dy = y - ci.qy, dz = z - ci.qz;
+                if (dx * dx + dy * dy + dz * dz < reach_sq)
                     {
-                    double x = p[u].x, y = p[u].y, z = p[u].z;
-                    tile_place(a.box, T, rc[u], x, y, z);
-                    txyz[3 * v[u] + 0] = x;
-                    txyz[3 * v[u] + 1] = y;
-                    txyz[3 * v[u] + 2] = z;
-                    if (!SINGLE_TYPE)
-                        ttype[v[u]] = (unsigned char)hmd_double_as_uint(p[u].w);
+                    x += ci.sx;
+                    y += ci.sy;
+                    z += ci.sz;
                     }
+                else
+                    tile_place(a.box, T, rc, x, y, z);
+                const unsigned int v = tile_slot(first + k);
+                txyz[v] = x;
+                txyz[v + 32] = y;
+                txyz[v + 64] = z;
+                if (!SINGLE_TYPE)
+                    ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
+                }
             }
         }
     else
@@ -169,17 +214,13 @@ __global__ void __launch_bounds__(PFT_THREADS)
                 p[q] = hmd_ld4(a.d_pos + idx[q]);
             if (round == 0 && my_h < H)
                 {
-                pft_home_t e;
-                e.idx = my_idx;
-                e.nn = 0;
-                e.row = 0;
-                e.lh = my_lh;
+                unsigned int nn = 0, row = 0;
                 if (my_idx < a.N)
                     {
-                    e.nn = a.d_n_neigh[my_idx];
-                    e.row = (unsigned int)(a.d_head_list[my_idx] / 4);
+                    nn = a.d_n_neigh[my_idx];
+                    row = (unsigned int)(a.d_head_list[my_idx] / 4);
                     }
-                s_home[my_h] = e;
+                s_home[my_h] = pft_home(my_idx, nn, row, tile_slot(my_lh));
                 }
     #pragma unroll
             for (int q = 0; q < PFT_BATCH; q++)
@@ -187,12 +228,12 @@ __global__ void __launch_bounds__(PFT_THREADS)
                 const unsigned int rc = rc0 + q;
                 if (on[q])
                     {
-                    const unsigned int v = T.off[rc] + lane;
+                    const unsigned int v = tile_slot(T.off[rc] + lane);
                     double x = p[q].x, y = p[q].y, z = p[q].z;
                     tile_place(a.box, T, rc, x, y, z);
-                    txyz[3 * v + 0] = x;
-                    txyz[3 * v + 1] = y;
-                    txyz[3 * v + 2] = z;
+                    txyz[v] = x;
+                    txyz[v + 32] = y;
+                    txyz[v + 64] = z;
                     if (!SINGLE_TYPE)
                         ttype[v] = (unsigned char)hmd_double_as_uint(p[q].w);
                     }
@@ -206,12 +247,12 @@ __global__ void __launch_bounds__(PFT_THREADS)
                 {
                 const unsigned int j = g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + k];
                 const double4 pp = hmd_ld4(a.d_pos + j);
-                const unsigned int v = T.off[rc] + k;
+                const unsigned int v = tile_slot(T.off[rc] + k);
                 double x = pp.x, y = pp.y, z = pp.z;
                 tile_place(a.box, T, rc, x, y, z);
-                txyz[3 * v + 0] = x;
-                txyz[3 * v + 1] = y;
-                txyz[3 * v + 2] = z;
+                txyz[v] = x;
+                txyz[v + 32] = y;
+                txyz[v + 64] = z;
                 if (!SINGLE_TYPE)
                     ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
                 }
@@ -220,39 +261,42 @@ __global__ void __launch_bounds__(PFT_THREADS)
             {
             unsigned int rc_home;
             const unsigned int lh = home_local(h, rc_home);
-            pft_home_t e;
-            e.idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
-            e.nn = 0;
-            e.row = 0;
-            e.lh = lh;
-            if (e.idx < a.N)
+            const unsigned int idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
+            unsigned int nn = 0, row = 0;
+            if (idx < a.N)
                 {
-                e.nn = a.d_n_neigh[e.idx];
-                e.row = (unsigned int)(a.d_head_list[e.idx] / 4);
+                nn = a.d_n_neigh[idx];
+                row = (unsigned int)(a.d_head_list[idx] / 4);
                 }
-            s_home[h] = e;
+            s_home[h] = pft_home(idx, nn, row, tile_slot(lh));
             }
         }
     if (threadIdx.x == 0)
         {
-        txyz[3 * total + 0] = 1e30;
-        txyz[3 * total + 1] = 1e30;
-        txyz[3 * total + 2] = 1e30;
+        s_home[H] = pft_home_t {0u, 0u, 0u};
+        const unsigned int v = tile_slot(total);
+        txyz[v] = 1e30;
+        txyz[v + 32] = 1e30;
+        txyz[v + 64] = 1e30;
         if (!SINGLE_TYPE)
-            ttype[total] = 0;
+            ttype[v] = 0;
         }
     __syncthreads();
 
     // ---- forces: groups of TPP lanes take home particles from a shared counter.  A row is fetched
-    // whole (PFT_CH chunks of four entries per lane) one home particle ahead of its use: rows stream
+    // whole (PFT_CH chunks of four entries per lane) two home particles ahead of its use: rows stream
     // from HBM exactly once, so what bounds this phase is the number of bytes in flight. ----
     constexpr int PFT_CH = 4;
+#ifdef HMD_PFT_STAGE_ONLY
+    if (total != 0xdeadbeefu)
+        return;
+#endif
     const unsigned int sub = threadIdx.x % TPP;
     const unsigned int leader = (lane / TPP) * TPP;
     const unsigned char* rows = reinterpret_cast<const unsigned char*>(d_tile_nlist);
-    const pft_home_t none = {0u, 0u, 0u, 0u};
-    // Rows are padded to a multiple of four entries with 0xffff (-> the dummy slot).  Chunks past the
-    // end of a row read the following rows or the 512-byte slack after the last one; never used.
+    // Rows are padded to a multiple of four entries with the dummy's slot.  Chunks past the end of a
+    // row read the following rows or the 512-byte slack after the last one; never used.
+    const unsigned int three = 3u;
     auto fetch = [&](const pft_home_t& e, uint2 (&c)[PFT_CH])
     {
         const uint2* row = reinterpret_cast<const uint2*>(rows) + e.row;
@@ -260,36 +304,38 @@ __global__ void __launch_bounds__(PFT_THREADS)
         for (int q = 0; q < PFT_CH; q++)
             c[q] = row[sub + TPP * q];
     };
-    unsigned int h = threadIdx.x / TPP;
-    pft_home_t e = (h < H) ? s_home[h] : none;
-    uint2 cur[PFT_CH];
-    fetch(e, cur);
-    while (h < H)
-        {
+    auto grab = [&](unsigned int& h, pft_home_t& e, uint2 (&c)[PFT_CH])
+    {
         unsigned int nh = 0;
         if (sub == 0)
             nh = atomicAdd(&s_next, 1u);
-        const unsigned int h_next = __shfl(nh, leader, 64);
-        const pft_home_t e_next = (h_next < H) ? s_home[h_next] : none;
-        uint2 nxt[PFT_CH];
-        fetch(e_next, nxt);
-
-        const unsigned int lh = e.lh;
+        h = __shfl(nh, leader, 64);
+        e = s_home[min(h, H)]; // s_home[H] is an empty entry
+        fetch(e, c);
+    };
+    auto process = [&](const pft_home_t& e, const uint2 (&cur)[PFT_CH])
+    {
+        const unsigned int lh = e.nn_lh >> 16;
         pf_accum acc;
-        const unsigned int nn = e.nn;
-        const double xi = txyz[3 * lh], yi = txyz[3 * lh + 1], zi = txyz[3 * lh + 2];
+        const unsigned int nn = e.nn_lh & 0xffffu;
+        const double xi = txyz[lh], yi = txyz[lh + 32], zi = txyz[lh + 64];
         const unsigned int ti = SINGLE_TYPE ? 0u : (unsigned int)ttype[lh];
         auto chunk = [&](uint2 w)
         {
-            unsigned int j[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#ifdef HMD_PFT_SKELETON
+            acc.fx += (double)(w.x ^ w.y);
+            return;
+#endif
+            const unsigned int j[4] = {pft_slot_bytes<0>(w.x, three), pft_slot_bytes<1>(w.x, three), pft_slot_bytes<0>(w.y, three), pft_slot_bytes<1>(w.y, three)};
             double xj[4], yj[4], zj[4];
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 {
-                j[m] = min(j[m], total);
-                xj[m] = txyz[3 * j[m]];
-                yj[m] = txyz[3 * j[m] + 1];
-                zj[m] = txyz[3 * j[m] + 2];
+                // three 8-byte reads: paired 16-byte LDS reads run at half the rate (volatile keeps them apart)
+                pft_lds_double* c = (pft_lds_double*)(size_t)j[m];
+                xj[m] = c[0];
+                yj[m] = *(volatile pft_lds_double*)(c + 32);
+                zj[m] = *(volatile pft_lds_double*)(c + 64);
                 }
 #pragma unroll
             for (int m = 0; m < 4; m++)
@@ -304,7 +350,7 @@ __global__ void __launch_bounds__(PFT_THREADS)
                     }
                 else
                     {
-                    const unsigned int tp = (unsigned int)ttype[j[m]] * a.ntypes + ti;
+                    const unsigned int tp = (unsigned int)ttype[j[m] >> 3] * a.ntypes + ti;
                     rcutsq = s_rcutsq[tp];
                     if (SHIFT == 2)
                         ronsq = s_ronsq[tp];
@@ -320,21 +366,39 @@ __global__ void __launch_bounds__(PFT_THREADS)
         // rows longer than PFT_CH * 4 * TPP entries
         for (unsigned int k = 4 * (sub + TPP * PFT_CH); k < nn; k += 4 * TPP)
             chunk((reinterpret_cast<const uint2*>(rows) + e.row)[k / 4]);
-
         pf_finish<VIRIAL, TPP>(acc, a, e.idx, e.idx < a.N && sub == 0);
-        h = h_next;
-        e = e_next;
-#pragma unroll
-        for (int q = 0; q < PFT_CH; q++)
-            cur[q] = nxt[q];
+    };
+    // Three row buffers in rotation: while one home particle is computed, the rows of the next two
+    // are on their way.  The counter hands out increasing numbers, so a group is done at the first
+    // number past the end.
+    constexpr unsigned int groups = PFT_THREADS / TPP;
+    unsigned int h0 = threadIdx.x / TPP, h1 = h0 + groups, h2;
+    pft_home_t e0 = s_home[min(h0, H)], e1 = s_home[min(h1, H)], e2;
+    uint2 b0[PFT_CH], b1[PFT_CH], b2[PFT_CH];
+    fetch(e0, b0);
+    fetch(e1, b1);
+    for (;;)
+        {
+        if (h0 >= H)
+            break;
+        grab(h2, e2, b2);
+        process(e0, b0);
+        if (h1 >= H)
+            break;
+        grab(h0, e0, b0);
+        process(e1, b1);
+        if (h2 >= H)
+            break;
+        grab(h1, e1, b1);
+        process(e2, b2);
         }
     }
 
 template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned int ntypes, unsigned int cell_Nmax)
     {
-    size_t b = ((size_t)cap + 1) * 24 + (size_t)TL_NH * cell_Nmax * sizeof(pft_home_t);
+    size_t b = (size_t)tile_doubles(cap) * 8 + PFT_TABLES + ((size_t)TL_NH * cell_Nmax + 1) * sizeof(pft_home_t);
     if (ntypes > 1)
-        b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + cap + 1;
+        b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + tile_doubles(cap);
     return (b + 15) / 16 * 16;
     }
 

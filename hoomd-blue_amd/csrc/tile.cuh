@@ -29,6 +29,23 @@ constexpr int TL_RC = TR_X * TR_Y * TR_Z; // region cells, at most 64 (one wave 
 constexpr int TL_NH = TB_X * TB_Y * TB_Z; // home cells
 static_assert(TL_RC <= 64, "the region must fit one wave");
 
+// Where candidate v lives in an LDS tile of doubles: blocks of 32 candidates, each block 32 x, then
+// 32 y, then 32 z.  Lanes that read neighboring candidates hit neighboring banks, and one 16-bit
+// number (tile rows store it) addresses all three coordinates: x at [s], y at [s + 32], z at [s + 64].
+__host__ __device__ constexpr unsigned int tile_slot(unsigned int v)
+    {
+    return v + 64u * (v >> 5);
+    }
+__host__ __device__ constexpr unsigned int tile_unslot(unsigned int s)
+    {
+    return (s / 96u) * 32u + s % 96u;
+    }
+// doubles in a tile that holds candidates 0..cap (cap itself is the dummy entry)
+__host__ __device__ constexpr unsigned int tile_doubles(unsigned int cap)
+    {
+    return (cap / 32u + 1u) * 96u;
+    }
+
 // region cell number of region coordinates, and of home cell hc = (hz*TB_Y + hy)*TB_X + hx
 __host__ __device__ constexpr int tile_rc(int rx, int ry, int rz)
     {
@@ -43,10 +60,20 @@ struct tile_tables
     {
     unsigned int off[65];        // exclusive prefix of the region's cell sizes; off[TL_RC..64] = total
     int cell[TL_RC];             // grid cell of a region cell, -1 when outside a non-periodic grid
-    // centre of the region cell in fractional box coordinates, from its UNWRAPPED grid coordinate
-    // (below 0 or above 1 for a periodic image): a member at fraction f is seen in image rint(fc - f)
-    double fcx[TL_RC], fcy[TL_RC], fcz[TL_RC];
+    // Per axis d and region coordinate r (rc = (rz*TR_Y + ry)*TR_X + rx):
+    // fc: centre of the region cell in fractional box coordinates, from its UNWRAPPED grid coordinate
+    // (below 0 or above 1 for a periodic image): a member at fraction f is seen in image rint(fc - f);
+    // img: the image a member that has not crossed the box boundary since binning is seen in.
+    double fc[3][4], img[3][4];
     };
+static_assert(TR_X <= 4 && TR_Y <= 4 && TR_Z <= 4, "tile_tables holds four region coordinates per axis");
+
+__device__ __forceinline__ void tile_rc_coords(unsigned int rc, unsigned int& rx, unsigned int& ry, unsigned int& rz)
+    {
+    rx = rc % TR_X;
+    ry = (rc / TR_X) % TR_Y;
+    rz = rc / (TR_X * TR_Y);
+    }
 
 __device__ __forceinline__ unsigned int tile_xcd_remap(unsigned int b, unsigned int nb)
     {
@@ -130,11 +157,14 @@ __device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_b
         if (t == 63)
             T.off[64] = incl;
         if (t < TL_RC)
-            {
-            T.fcx[t] = (cx0 - 1 + t % TR_X + 0.5) / (double)g.ci.w;
-            T.fcy[t] = (cy0 - 1 + (t / TR_X) % TR_Y + 0.5) / (double)g.ci.h;
-            T.fcz[t] = (cz0 - 1 + t / (TR_X * TR_Y) + 0.5) / (double)g.ci.d;
             T.cell[t] = cell;
+        if (t < 12)
+            {
+            const int d = t / 4, r = t % 4;
+            const int c = (d == 0 ? cx0 : d == 1 ? cy0 : cz0) - 1 + r;
+            const int dim = (int)(d == 0 ? g.ci.w : d == 1 ? g.ci.h : g.ci.d);
+            T.fc[d][r] = (c + 0.5) / (double)dim;
+            T.img[d][r] = !box.periodic[d] ? 0.0 : c < 0 ? -1.0 : c >= dim ? 1.0 : 0.0;
             }
         }
     }
@@ -144,17 +174,66 @@ __device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_b
 // particle that leaves the box, which moves it by a box vector without changing its cell-list slot.
 // image = r + ix*a1 + iy*a2 + iz*a3, a1 = (Lx,0,0), a2 = (xy*Ly, Ly, 0), a3 = (xz*Lz, yz*Lz, Lz)
 // (hoomd/BoxDim.h:391-458).
-__device__ __forceinline__ void tile_place(const hmd_box_t& box, const tile_tables& T, unsigned int rc, double& x, double& y, double& z)
+__device__ __forceinline__ void tile_shift(const hmd_box_t& box, double ix, double iy, double iz, double& x, double& y, double& z)
     {
-    hmd_scalar3 zero;
-    zero.x = zero.y = zero.z = 0.0;
-    const double3 f = hmd_make_fraction(box, x, y, z, zero);
-    const double ix = box.periodic[0] ? rint(T.fcx[rc] - f.x) : 0.0;
-    const double iy = box.periodic[1] ? rint(T.fcy[rc] - f.y) : 0.0;
-    const double iz = box.periodic[2] ? rint(T.fcz[rc] - f.z) : 0.0;
     x += ix * box.L[0] + iy * (box.L[1] * box.xy) + iz * (box.L[2] * box.xz);
     y += iy * box.L[1] + iz * (box.L[2] * box.yz);
     z += iz * box.L[2];
+    }
+
+__device__ __forceinline__ void tile_place(const hmd_box_t& box, const tile_tables& T, unsigned int rc, double& x, double& y, double& z)
+    {
+    unsigned int rx, ry, rz;
+    tile_rc_coords(rc, rx, ry, rz);
+    // fractional coordinates (hoomd/BoxDim.h:260-268 without ghost width); only their rounding matters here
+    const double fx = ((x - box.lo[0]) - ((box.xz - box.yz * box.xy) * z + box.xy * y)) * box.Linv[0];
+    const double fy = ((y - box.lo[1]) - box.yz * z) * box.Linv[1];
+    const double fz = (z - box.lo[2]) * box.Linv[2];
+    const double ix = box.periodic[0] ? rint(T.fc[0][rx] - fx) : 0.0;
+    const double iy = box.periodic[1] ? rint(T.fc[1][ry] - fy) : 0.0;
+    const double iz = box.periodic[2] ? rint(T.fc[2][rz] - fz) : 0.0;
+    tile_shift(box, ix, iy, iz, x, y, z);
+    }
+
+// What tile_place computes for every member of one region cell, split into the part that depends on
+// the cell only.  A member that has not crossed the box boundary since binning sits in image
+// T.img of the cell; that is also what tile_place returns for it whenever the shifted member lies
+// within `reach` of the cell's centre, reach < half the smallest distance between opposite box faces:
+// then every fractional coordinate of (member - centre) is below 1/2 in magnitude and rounds to zero.
+struct tile_cell_image
+    {
+    double sx, sy, sz; // shift of the cell's image
+    double qx, qy, qz; // centre of the region cell minus that shift
+    };
+
+__device__ __forceinline__ tile_cell_image tile_cell_setup(const hmd_box_t& box, const tile_tables& T, unsigned int rc)
+    {
+    unsigned int rx, ry, rz;
+    tile_rc_coords(rc, rx, ry, rz);
+    tile_cell_image c;
+    c.sx = c.sy = c.sz = 0.0;
+    tile_shift(box, T.img[0][rx], T.img[1][ry], T.img[2][rz], c.sx, c.sy, c.sz);
+    // centre in Cartesian coordinates (hoomd/BoxDim.h:282-288)
+    const double vz = box.lo[2] + T.fc[2][rz] * box.L[2];
+    const double vy = box.lo[1] + T.fc[1][ry] * box.L[1];
+    c.qx = box.lo[0] + T.fc[0][rx] * box.L[0] + (box.xy * vy + box.xz * vz);
+    c.qy = vy + box.yz * vz;
+    c.qz = vz;
+    c.qx -= c.sx;
+    c.qy -= c.sy;
+    c.qz -= c.sz;
+    return c;
+    }
+
+// squared reach for tile_cell_image: (0.49 * smallest periodic face distance)^2
+__device__ __forceinline__ double tile_reach_sq(const hmd_box_t& box)
+    {
+    double m = 1e300;
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+        if (box.periodic[d])
+            m = fmin(m, box.nearest_plane[d]);
+    return m >= 1e150 ? 1e300 : 0.2401 * m * m;
     }
 
 // region cell that holds candidate v (off[rc] <= v < off[rc+1]); empty cells are skipped

@@ -274,6 +274,7 @@ def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, sh
     if fast:
         cpos = tile_refresh(pos, tl)
         geom.d_cpos, geom.d_slot_meta = ptr(cpos), ptr(tl["slot_meta"])
+        geom.capacity = max(int(tl["overflow"][1].item()), 1)  # the largest region the build saw: the exact LDS need
     check(fn(C.byref(a), C.byref(geom), ptr(tl["tiles"]), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_%s_tiles" % evaluator)
     return force, virial
 

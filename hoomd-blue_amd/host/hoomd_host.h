@@ -856,6 +856,11 @@ class NeighborListGPUBinned : public Compute
         {
         return m_tiles_active;
         }
+    //! largest number of particles any tile region held at the last build
+    unsigned int getTileCapacity() const
+        {
+        return m_tile_capacity;
+        }
     void setTilesEnabled(bool b)
         {
         m_tiles_enabled = b;

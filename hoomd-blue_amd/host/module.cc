@@ -298,6 +298,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property_readonly("num_builds", &NeighborListGPUBinned::getNumUpdates)
         .def_property("tiles", &NeighborListGPUBinned::getTilesEnabled, &NeighborListGPUBinned::setTilesEnabled)
         .def_property_readonly("tiles_active", &NeighborListGPUBinned::tilesActive)
+        .def_property_readonly("tile_capacity", &NeighborListGPUBinned::getTileCapacity)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)
         .def("setFilterBody", &NeighborListGPUBinned::setFilterBody)

@@ -24,7 +24,7 @@ P = [orc.lj_params(1.0, 1.0)]
 if which in ("both", "tile"):
     tl = K.nlist_tiles(pos_t, N, gbox, [[2.5]], 0.4, cl, adj)
     for _ in range(3):
-        K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=False)
+        K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=False, fast=True)
 if which in ("both", "row"):
     nl = K.nlist_binned(pos_t, N, gbox, [[2.5]], 0.4, cl, adj)
     for _ in range(3):
