@@ -44,12 +44,20 @@ __global__ void __launch_bounds__(256) step_one_kernel(hmd_step_one_args_t a)
     double y = HMD_ADD(p.y, HMD_MUL(a.deltaT, vy));
     double z = HMD_ADD(p.z, HMD_MUL(a.deltaT, vz));
 
-    hmd_int3 img = a.d_image[idx];
-    hmd_wrap(a.box, x, y, z, img.x, img.y, img.z);
+    // few particles cross the box boundary in a step: touch the image only for those
+    hmd_int3 dimg = {0, 0, 0};
+    hmd_wrap(a.box, x, y, z, dimg.x, dimg.y, dimg.z);
 
     hmd_st4(a.d_pos + idx, x, y, z, p.w);
     hmd_st4(a.d_vel + idx, vx, vy, vz, v.w);
-    a.d_image[idx] = img;
+    if (dimg.x | dimg.y | dimg.z)
+        {
+        hmd_int3 img = a.d_image[idx];
+        img.x += dimg.x;
+        img.y += dimg.y;
+        img.z += dimg.z;
+        a.d_image[idx] = img;
+        }
     }
 
 __global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
@@ -111,11 +119,19 @@ template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_st
         double x = HMD_ADD(p.x, HMD_MUL(a.one.deltaT, vx));
         double y = HMD_ADD(p.y, HMD_MUL(a.one.deltaT, vy));
         double z = HMD_ADD(p.z, HMD_MUL(a.one.deltaT, vz));
-        hmd_int3 img = a.one.d_image[idx];
-        hmd_wrap(a.one.box, x, y, z, img.x, img.y, img.z);
+        // few particles cross the box boundary in a step: touch the image only for those
+        hmd_int3 dimg = {0, 0, 0};
+        hmd_wrap(a.one.box, x, y, z, dimg.x, dimg.y, dimg.z);
         hmd_st4(a.one.d_pos + idx, x, y, z, p.w);
         hmd_st4(a.one.d_vel + idx, vx, vy, vz, v.w);
-        a.one.d_image[idx] = img;
+        if (dimg.x | dimg.y | dimg.z)
+            {
+            hmd_int3 img = a.one.d_image[idx];
+            img.x += dimg.x;
+            img.y += dimg.y;
+            img.z += dimg.z;
+            a.one.d_image[idx] = img;
+            }
         if (a.d_cpos)
             hmd_st4(a.d_cpos + a.d_slot_of[idx], x, y, z, p.w);
         // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
