@@ -111,7 +111,8 @@ template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_st
         double vx = HMD_ADD(HMD_MUL(v.x, a.two.rescale_factor), HMD_MUL(hdt, acc.x));
         double vy = HMD_ADD(HMD_MUL(v.y, a.two.rescale_factor), HMD_MUL(hdt, acc.y));
         double vz = HMD_ADD(HMD_MUL(v.z, a.two.rescale_factor), HMD_MUL(hdt, acc.z));
-        a.two.d_accel[idx] = acc;
+        if (a.two.d_accel)
+            a.two.d_accel[idx] = acc;
         // ---- step one (t+1) ----
         vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), a.one.rescale_factor);
         vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), a.one.rescale_factor);
@@ -316,7 +317,7 @@ extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, voi
     {
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: args is NULL");
     const hmd_fused_step_args_t& a = *args;
-    HMD_REQUIRE(a.two.d_vel && a.two.d_accel && a.two.d_net_force && a.one.d_pos && a.one.d_vel && a.one.d_accel && a.one.d_image,
+    HMD_REQUIRE(a.two.d_vel && a.two.d_net_force && a.one.d_pos && a.one.d_vel && a.one.d_image,
                 HMD_ERR_INVALID_ARGUMENT, "hmd_nve_step_two_one_check: pos, vel, accel, image and net_force are required");
     HMD_REQUIRE(a.two.d_vel == a.one.d_vel && a.two.d_accel == a.one.d_accel && a.two.d_group_members == a.one.d_group_members
                     && a.two.group_size == a.one.group_size,

@@ -76,7 +76,10 @@ void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     hmd_fused_step_args_t a;
     std::memset(&a, 0, sizeof(a));
     a.two.d_vel = m_pdata->vel();
-    a.two.d_accel = m_pdata->accel();
+    // the fused pass carries the acceleration from its second-half part to its first-half part in
+    // registers; the array is brought up to date by the separate second half step that ends every
+    // sequence of fused passes (IntegratorTwoStep::flush)
+    a.two.d_accel = nullptr;
     a.two.d_group_members = m_group->getIndexArray();
     a.two.group_size = m_group->getNumMembers();
     a.two.d_net_force = m_pdata->netForceForIntegration();
@@ -84,7 +87,7 @@ void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     a.two.rescale_factor = 1.0;
     a.one.d_pos = m_pdata->pos();
     a.one.d_vel = m_pdata->vel();
-    a.one.d_accel = m_pdata->accel();
+    a.one.d_accel = nullptr;
     a.one.d_image = m_pdata->image();
     a.one.d_group_members = a.two.d_group_members;
     a.one.group_size = a.two.group_size;

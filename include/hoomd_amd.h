@@ -388,7 +388,10 @@ int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
    skips the check; otherwise the group must be every particle (d_group_members NULL,
    group_size == check.N).  With check.d_published set, (stamp << 32 | *d_result) is published by a
    one-wave kernel queued behind the pass.  With d_cpos / d_slot_of set, the new position of particle i
-   is also stored at d_cpos[d_slot_of[i]] (what hmd_tile_refresh would do afterwards). */
+   is also stored at d_cpos[d_slot_of[i]] (what hmd_tile_refresh would do afterwards).
+   two.d_accel may be NULL (one.d_accel is never read: the acceleration passes from the second-half
+   part to the first-half part in registers): the accelerations of time t are then not stored, and a
+   caller that needs the array runs hmd_nvt_rescale_step_two on its own for the last step. */
 typedef struct
     {
     hmd_step_two_args_t two;
