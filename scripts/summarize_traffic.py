@@ -1,10 +1,10 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kilobytes per dispatch).
 
 FETCH_SIZE on gfx950 tallies 128-byte requests at 64 bytes for wide coalesced loads; other widths are
-uncalibrated.  The fused integration kernel has a known, purely streaming byte count per particle
-(reads pos 32 + vel 32 + net force 32 + image 12 + last_pos 32 = 140 B, writes pos 32 + vel 32 + accel 24
-+ image 12 = 100 B), so its counters calibrate the read and write scale in this very run; the same scale
-is applied to the other kernels."""
+uncalibrated.  The stand-alone second half step has a known, purely streaming byte count per particle
+(reads vel 32 + net force 32 = 64 B, writes vel 32 + accel 24 = 56 B), so its counters calibrate the read
+and write scale in this very run; the same scale is applied to the other kernels.  (Cross-check: the fused
+integration pass then comes out at its own count, reads 132 B and writes 96 B per particle.)"""
 import collections
 import csv
 import glob
@@ -49,17 +49,17 @@ for name in set(fetch) | set(write):
     rows[k] = {"launches": len(f), "fetch_kb": sum(f) / max(len(f), 1), "write_kb": sum(w) / max(len(w), 1)}
 
 cal = {"read_scale": None, "write_scale": None}
-if "fused_step_kernel" in rows:
-    r = rows["fused_step_kernel"]
-    cal["read_scale"] = 140.0 * N / (r["fetch_kb"] * 1024.0)
-    cal["write_scale"] = 100.0 * N / (r["write_kb"] * 1024.0)
+if "step_two_kernel" in rows:
+    r = rows["step_two_kernel"]
+    cal["read_scale"] = 64.0 * N / (r["fetch_kb"] * 1024.0)
+    cal["write_scale"] = 56.0 * N / (r["write_kb"] * 1024.0)
 for k, r in rows.items():
     rs = cal["read_scale"] or 2.0
     ws = cal["write_scale"] or 1.0
     r["hbm_bytes_per_launch"] = (r["fetch_kb"] * rs + r["write_kb"] * ws) * 1024.0
     r["hbm_bytes_per_particle"] = r["hbm_bytes_per_launch"] / N
 summary = {"N": N, "calibration": cal, "kernels": rows,
-           "note": "FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; scales calibrated on the fused integration kernel "
+           "note": "FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; scales calibrated on the stand-alone second half step "
                    "(known streaming byte count) in the same runs"}
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
