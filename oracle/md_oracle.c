@@ -898,6 +898,98 @@ void orc_pair_forces(int ev,
     }
 
 /* ------------------------------------------------------------------------------------ */
+/* bonds                                                                                */
+/* ------------------------------------------------------------------------------------ */
+
+/* hoomd/md/EvaluatorBondFENE.h:90-94 (constructor) and :116-156 (evalForceAndEnergy) */
+int orc_eval_bond_fene(double rsq, const double* p, double* force_divr, double* bond_eng)
+    {
+    const double K = p[0], r_0 = p[1], sigma_6 = p[2], epsilon_x_4 = p[3], delta = p[4];
+    const double lj1 = epsilon_x_4 * sigma_6 * sigma_6;
+    const double lj2 = epsilon_x_4 * sigma_6;
+    double rmdoverr;
+    const double rtemp = sqrt(rsq) - delta;
+    rmdoverr = rtemp / sqrt(rsq);
+    rsq = rtemp * rtemp;
+    const double r2inv = 1.0 / rsq;
+    const double r6inv = r2inv * r2inv * r2inv;
+    double wca_divr = 0.0, pair_eng = 0.0;
+    const double sigma6inv = lj2 / lj1;
+    const double epsilon = lj2 * lj2 / 4.0 / lj1;
+    if (lj1 != 0 && r6inv > sigma6inv / 2.0)
+        {
+        wca_divr = r2inv * r6inv * (12.0 * lj1 * r6inv - 6.0 * lj2);
+        pair_eng = (r6inv * (lj1 * r6inv - lj2) + epsilon);
+        }
+    *force_divr = wca_divr * rmdoverr;
+    *bond_eng = pair_eng;
+    if (K != 0.0)
+        {
+        if (rsq >= r_0 * r_0)
+            return 0;
+        *force_divr += -K / (1.0 - rsq / (r_0 * r_0)) * rmdoverr;
+        *bond_eng += -0.5 * K * (r_0 * r_0) * log(1.0 - rsq / (r_0 * r_0));
+        }
+    return 1;
+    }
+
+/* hoomd/md/PotentialBond.h:165-336: loop over bonds, both ends receive the force and half the energy */
+int orc_bond_forces_fene(const orc_d4* pos, const unsigned int* rtag, unsigned int N, unsigned int n_total, const orc_box_t* box,
+                         const unsigned int* bonds, const unsigned int* bond_type, unsigned int n_bonds, const double* params,
+                         int compute_virial, orc_d4* force, double* virial, size_t vp)
+    {
+    memset(force, 0, sizeof(orc_d4) * n_total);
+    if (virial)
+        memset(virial, 0, sizeof(double) * 6 * vp);
+    for (unsigned int i = 0; i < n_bonds; i++)
+        {
+        const unsigned int a = rtag[bonds[2 * i]], b = rtag[bonds[2 * i + 1]];
+        if (a >= n_total || b >= n_total)
+            return (int)(1 + i);
+        double dx[3] = {pos[b].x - pos[a].x, pos[b].y - pos[a].y, pos[b].z - pos[a].z};
+        orc_box_min_image(box, dx);
+        const double rsq = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+        double force_divr = 0.0, bond_eng = 0.0;
+        const int evaluated = orc_eval_bond_fene(rsq, params + 5 * bond_type[i], &force_divr, &bond_eng);
+        bond_eng *= 0.5;
+        if (!evaluated)
+            return (int)(1 + i);
+        double bv[6] = {0, 0, 0, 0, 0, 0};
+        if (compute_virial)
+            {
+            const double f2 = 0.5 * force_divr;
+            bv[0] = dx[0] * dx[0] * f2;
+            bv[1] = dx[0] * dx[1] * f2;
+            bv[2] = dx[0] * dx[2] * f2;
+            bv[3] = dx[1] * dx[1] * f2;
+            bv[4] = dx[1] * dx[2] * f2;
+            bv[5] = dx[2] * dx[2] * f2;
+            }
+        if (b < N)
+            {
+            force[b].x += force_divr * dx[0];
+            force[b].y += force_divr * dx[1];
+            force[b].z += force_divr * dx[2];
+            force[b].w += bond_eng;
+            if (compute_virial)
+                for (int c = 0; c < 6; c++)
+                    virial[c * vp + b] += bv[c];
+            }
+        if (a < N)
+            {
+            force[a].x -= force_divr * dx[0];
+            force[a].y -= force_divr * dx[1];
+            force[a].z -= force_divr * dx[2];
+            force[a].w += bond_eng;
+            if (compute_virial)
+                for (int c = 0; c < 6; c++)
+                    virial[c * vp + a] += bv[c];
+            }
+        }
+    return 0;
+    }
+
+/* ------------------------------------------------------------------------------------ */
 /* integrator                                                                           */
 /* ------------------------------------------------------------------------------------ */
 

@@ -204,6 +204,25 @@ void orc_pair_forces(int evaluator,
                      double* virial,
                      size_t virial_pitch);
 
+/* ---- bonds (hoomd/md/EvaluatorBondFENE.h, hoomd/md/PotentialBond.h) ---- */
+/* params5: {k, r_0, sigma_6, epsilon_x_4, delta} (fene_params, EvaluatorBondFENE.h:30-69) */
+int orc_eval_bond_fene(double rsq, const double* params5, double* force_divr, double* bond_eng);
+/* Returns 0, or 1 + the number of the first bond whose energy is undefined (the reference throws
+   "bond out of bounds" there, PotentialBond.h:330-336).  bonds: 2 tags per bond; bond_type per bond. */
+int orc_bond_forces_fene(const orc_d4* pos,
+                         const unsigned int* rtag,
+                         unsigned int N,
+                         unsigned int n_total,
+                         const orc_box_t* box,
+                         const unsigned int* bonds,
+                         const unsigned int* bond_type,
+                         unsigned int n_bonds,
+                         const double* params, /* 5 per bond type */
+                         int compute_virial,
+                         orc_d4* force,
+                         double* virial,
+                         size_t virial_pitch);
+
 /* ---- integrator ---- */
 void orc_sum_net_force(orc_d4* net_force,
                        double* net_virial,

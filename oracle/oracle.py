@@ -327,6 +327,38 @@ def eval_lrc(ev, rcutsq, params2):
     return e.value, pr.value
 
 
+def fene_params(k, r0, epsilon, sigma, delta):
+    """hoomd/md/EvaluatorBondFENE.h:47-56: (k, r_0, sigma_6, epsilon_x_4, delta)."""
+    return (k, r0, sigma * sigma * sigma * sigma * sigma * sigma, 4.0 * epsilon, delta)
+
+
+def eval_bond_fene(rsq, params5):
+    f = C.c_double(0.0)
+    e = C.c_double(0.0)
+    ok = _lib.orc_eval_bond_fene(C.c_double(rsq), (C.c_double * 5)(*params5), C.byref(f), C.byref(e))
+    return bool(ok), f.value, e.value
+
+
+def bond_forces_fene(pos, rtag, N, box, bonds, bond_type, params, compute_virial=True, n_total=None):
+    """Forces, half energies and virials of FENE + WCA bonds (hoomd/md/PotentialBond.h:165-336).  Raises
+    RuntimeError where the reference throws "bond out of bounds"."""
+    n_total = pos.shape[0] if n_total is None else n_total
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    rtag = np.ascontiguousarray(rtag, dtype=np.uint32)
+    bonds = np.ascontiguousarray(bonds, dtype=np.uint32).reshape(-1, 2)
+    bond_type = np.ascontiguousarray(bond_type, dtype=np.uint32)
+    prm = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 5)
+    force = np.zeros((n_total, 4))
+    virial = np.zeros((6, n_total))
+    rc = _lib.orc_bond_forces_fene(_p(pos, C.c_double), _p(rtag, C.c_uint), C.c_uint(N), C.c_uint(n_total), C.byref(box),
+                                   _p(bonds, C.c_uint), _p(bond_type, C.c_uint), C.c_uint(len(bonds)), _p(prm, C.c_double),
+                                   C.c_int(int(compute_virial)), _p(force, C.c_double), _p(virial, C.c_double),
+                                   C.c_size_t(n_total))
+    if rc:
+        raise RuntimeError("Error in bond calculation: bond %d out of bounds" % (rc - 1))
+    return force, virial
+
+
 def lj_params(sigma, epsilon):
     """hoomd/md/EvaluatorPairLJ.h:136-140."""
     return (sigma * sigma * sigma * sigma * sigma * sigma, 4.0 * epsilon)

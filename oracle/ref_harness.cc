@@ -6,6 +6,7 @@
 //   hoomd/Index1D.h           Index2D / Index3D
 //   hoomd/md/EvaluatorPairLJ.h                              evalForceAndEnergy, LRC integrals
 //   example_plugins/pair_plugin/EvaluatorPairExample.h      evalForceAndEnergy
+//   hoomd/md/EvaluatorBondFENE.h                            evalForceAndEnergy
 // Doubles are written as C99 hex floats so the vectors are bit-exact.
 //
 // Build recipe: oracle/Makefile target `ref` (binary lands in oracle/_ref/, git-ignored).
@@ -15,6 +16,7 @@
 #include "hoomd/BoxDim.h"
 #include "hoomd/HOOMDMath.h"
 #include "hoomd/Index1D.h"
+#include "hoomd/md/EvaluatorBondFENE.h"
 #include "hoomd/md/EvaluatorPairLJ.h"
 #include "example_plugins/pair_plugin/EvaluatorPairExample.h"
 
@@ -220,6 +222,43 @@ int main()
         Index3D idx(w, h, d);
         printf("[%u,%u,%u,%u,%u,%u,%u,%u]%s", w, h, d, a, c, e, idx(a, c, e), idx.getNumElements(),
                i < 15 ? "," : "");
+        }
+    printf("],\n");
+
+    // ---------------- FENE + WCA bond evaluator (last: the sections above keep their random inputs) ----
+    printf("\"fene\": [\n");
+    const int n_fene = 300;
+    for (int i = 0; i < n_fene; i++)
+        {
+        EvaluatorBondFENE::param_type p;
+        p.k = (i % 29 == 0) ? 0.0 : uni(1.0, 40.0);
+        p.r_0 = uni(1.2, 2.5);
+        const double sigma = uni(0.7, 1.3), eps = (i % 31 == 0) ? 0.0 : uni(0.2, 2.0);
+        p.sigma_6 = sigma * sigma * sigma * sigma * sigma * sigma;
+        p.epsilon_x_4 = 4.0 * eps;
+        p.delta = (i % 3 == 0) ? 0.0 : uni(-0.5, 0.3);
+        // bond lengths from deep inside the WCA core to beyond r_0 (evaluated == false there)
+        const double r = uni(0.75, 1.15) * ((i % 17 == 0) ? p.r_0 + p.delta : 1.0) + ((p.delta > 0) ? p.delta : 0.0);
+        EvaluatorBondFENE ev(r * r, p);
+        Scalar f = 0, e = 0;
+        bool ok = ev.evalForceAndEnergy(f, e);
+        printf("{\"k\":");
+        pd(p.k);
+        printf(",\"r_0\":");
+        pd(p.r_0);
+        printf(",\"sigma_6\":");
+        pd(p.sigma_6);
+        printf(",\"epsilon_x_4\":");
+        pd(p.epsilon_x_4);
+        printf(",\"delta\":");
+        pd(p.delta);
+        printf(",\"rsq\":");
+        pd(r * r);
+        printf(",\"evaluated\":%d,\"force_divr\":", (int)ok);
+        pd(f);
+        printf(",\"bond_eng\":");
+        pd(e);
+        printf("}%s\n", i + 1 < n_fene ? "," : "");
         }
     printf("]\n}\n");
     return 0;

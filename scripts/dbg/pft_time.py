@@ -14,6 +14,10 @@ g = [(np.arange(k) + 0.5) * a - l / 2 for k, l in zip(n, L)]
 z, y, x = np.meshgrid(g[2], g[1], g[0], indexing="ij")
 xyz = np.stack([x.ravel(), y.ravel(), z.ravel()], 1) + np.random.default_rng(0).normal(0, 0.12, (x.size, 3))
 xyz = (xyz + L / 2) % L - L / 2
+# order particles by 4x4x4-site bricks so that neighbors in space are neighbors in memory (as the sorter does)
+ijk = np.stack(np.meshgrid(np.arange(n[2]), np.arange(n[1]), np.arange(n[0]), indexing="ij"), -1).reshape(-1, 3)
+key = ((ijk[:, 0] // 4) * (n[1] // 4) + ijk[:, 1] // 4) * (n[0] // 4) + ijk[:, 2] // 4
+xyz = xyz[np.argsort(key, kind="stable")]
 N = len(xyz)
 gbox, obox = A.Box.from_L(*L), orc.Box.from_L(*L)
 pos_t = torch.from_numpy(orc.pack_pos(xyz, np.zeros(N, int))).cuda()
@@ -34,7 +38,7 @@ pa.size_neigh_list = tl["tiles"].numel()
 cpos = K.tile_refresh(pos_t, tl)
 gfast = A.TileGeom.from_buffer_copy(tl["geom"])
 gfast.d_cpos, gfast.d_slot_meta, gfast.capacity = K.ptr(cpos), K.ptr(tl["slot_meta"]), cap
-for tpp in (8, 4):
+for tpp in (8,):
     pa.threads_per_particle = tpp
     for _ in range(3):
         A.check(fn(C.byref(pa), C.byref(gfast), K.ptr(tl["tiles"]), K.ptr(prm_t), None))

@@ -2,7 +2,10 @@
 
 * ref_header_vectors.json  -- printed by oracle/_ref/ref_harness, a program that compiles the
   reference's own header arithmetic (BoxDim.h, Index1D.h, EvaluatorPairLJ.h,
-  EvaluatorPairExample.h) where it lies under /root/reference.  Doubles are C99 hex floats.
+  EvaluatorPairExample.h, EvaluatorBondFENE.h) where it lies under /root/reference.  Doubles are
+  C99 hex floats.
+* bond_fenewca_cases.json -- the FENEWCA rows of the parameter table in the reference's
+  hoomd/md/pytest/test_bond.py (two particles 0.969 apart, expected force and energy to 1e-2).
 * lj_forces_and_energies.json -- the "LJ" rows of the reference's data file
   hoomd/md/pytest/forces_and_energies.json (Mathematica values at r = 0.75 and 1.5).
 * true_pair_list.json -- the reference's data file hoomd/md/pytest/true_pair_list.json
@@ -31,6 +34,18 @@ def main():
         fe = json.load(f)
     with open(os.path.join(HERE, "lj_forces_and_energies.json"), "w") as f:
         json.dump({"LJ": fe["LJ"], "distances": [0.75, 1.5], "r_cut": 2.5}, f, indent=1)
+
+    # the FENEWCA rows of bond_test_parameters (hoomd/md/pytest/test_bond.py:38-58), read as text
+    import re
+    text = open(os.path.join(REF, "hoomd/md/pytest/test_bond.py")).read()
+    rows = re.findall(r"hoomd\.md\.bond\.FENEWCA,\s*dict\(\),\s*dict\(([^)]*)\),\s*([-0-9.e]+),\s*([-0-9.e]+),", text)
+    cases = []
+    for params, force, energy in rows:
+        d = {k.strip(): float(v) for k, v in (kv.split("=") for kv in params.split(","))}
+        cases.append({"params": d, "distance": 0.969, "force": float(force), "energy": float(energy)})
+    assert len(cases) == 3
+    with open(os.path.join(HERE, "bond_fenewca_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
 
     shutil.copyfile(os.path.join(REF, "hoomd/md/pytest/true_pair_list.json"),
                     os.path.join(HERE, "true_pair_list.json"))

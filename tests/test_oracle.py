@@ -56,6 +56,40 @@ def test_example_evaluator_bit_exact(vec):
         assert f == fh(c["force_divr"]) and e == fh(c["pair_eng"])
 
 
+def test_fene_evaluator_bit_exact(vec):
+    # hoomd/md/EvaluatorBondFENE.h compiled from the reference's header
+    assert len(vec["fene"]) == 300
+    for c in vec["fene"]:
+        p = [float.fromhex(c[k]) for k in ("k", "r_0", "sigma_6", "epsilon_x_4", "delta")]
+        ok, f, e = orc.eval_bond_fene(float.fromhex(c["rsq"]), p)
+        assert ok == bool(c["evaluated"])
+        if ok:
+            assert f == float.fromhex(c["force_divr"]) and e == float.fromhex(c["bond_eng"])
+
+
+def test_fenewca_against_reference_test_values():
+    # the FENEWCA rows of hoomd/md/pytest/test_bond.py: two particles 0.969 apart along x in a box of 5
+    with open(os.path.join(G, "bond_fenewca_cases.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 3
+    for c in cases:
+        d = c["distance"]
+        pos = np.array([[-d / 2, 0, 0.1, 0], [d / 2, 0, 0.1, 0]], dtype=np.float64)
+        box = orc.Box.from_L(5, 5, 5)
+        force, virial = orc.bond_forces_fene(pos, [0, 1], 2, box, [[0, 1]], [0], [orc.fene_params(**c["params"])])
+        assert force[:, 3].sum() == pytest.approx(c["energy"], rel=1e-2)
+        np.testing.assert_allclose(force[0, :3], [c["force"], 0, 0], rtol=1e-2, atol=1e-5)
+        np.testing.assert_allclose(force[1, :3], [-c["force"], 0, 0], rtol=1e-2, atol=1e-5)
+        # virial: sum over both ends of 1/2 dx dx F/r = dx^2 F/r with dx = x1 - x0
+        assert virial[0].sum() == pytest.approx(-c["force"] * d, rel=1e-2)
+
+
+def test_bond_out_of_bounds_is_an_error():
+    pos = np.array([[-1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    with pytest.raises(RuntimeError):
+        orc.bond_forces_fene(pos, [0, 1], 2, orc.Box.from_L(10, 10, 10), [[0, 1]], [0], [orc.fene_params(30.0, 1.5, 1.0, 1.0, 0.0)])
+
+
 def test_box_arithmetic_bit_exact(vec):
     for b in vec["boxes"]:
         L = v3(b["L"])
