@@ -104,6 +104,17 @@ class UpdateExclusionArgs(C.Structure):
                 ("ex_list_indexer", Index2D), ("N", u32)]
 
 
+class BondTableArgs(C.Structure):
+    _fields_ = [("N", u32), ("n_total", u32), ("d_tag", vp), ("d_rtag", vp), ("d_tag_n_bonds", vp), ("d_tag_blist", vp),
+                ("tag_blist_idx", Index2D), ("d_n_bonds", vp), ("d_blist", vp), ("blist_idx", Index2D), ("d_flags", vp)]
+
+
+class BondArgs(C.Structure):
+    _fields_ = [("d_force", vp), ("d_virial", vp), ("virial_pitch", C.c_size_t), ("N", u32), ("d_pos", vp), ("box", Box),
+                ("d_blist", vp), ("blist_idx", Index2D), ("d_n_bonds", vp), ("n_bond_types", u32), ("d_flags", vp),
+                ("compute_virial", C.c_int)]
+
+
 class PairArgs(C.Structure):
     _fields_ = [("d_force", vp), ("d_virial", vp), ("virial_pitch", C.c_size_t), ("N", u32), ("n_max", u32),
                 ("d_pos", vp), ("d_charge", vp), ("box", Box), ("d_n_neigh", vp), ("d_nlist", vp), ("d_head_list", vp),
@@ -187,6 +198,8 @@ _SIGNATURES = {
     "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
     "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
+    "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),
+    "hmd_compute_bond_forces_fene": (C.c_int, [C.POINTER(BondArgs), vp, vp]),
     "hmd_compute_pair_forces_lj": (C.c_int, [C.POINTER(PairArgs), vp, vp]),
     "hmd_compute_pair_forces_example": (C.c_int, [C.POINTER(PairArgs), vp, vp]),
     "hmd_integrator_sum_net_force": (C.c_int, [C.POINTER(SumNetForceArgs), vp]),

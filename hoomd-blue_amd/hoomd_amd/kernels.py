@@ -279,6 +279,37 @@ def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, sh
     return force, virial
 
 
+def bond_table(tag, rtag, N, tag_n_bonds, tag_blist):
+    """Per-particle bond table in index order from the one keyed by tag (hmd_update_bond_table).
+    tag_blist: (max_bonds, n_tags, 2) int32 of (partner tag, bond type)."""
+    dev = tag.device
+    max_b, n_tags = tag_blist.shape[0], tag_blist.shape[1]
+    n_bonds = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+    blist = torch.zeros((max(max_b, 1), max(N, 1), 2), dtype=torch.int32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = _abi.BondTableArgs()
+    a.N, a.n_total, a.d_tag, a.d_rtag = N, tag.shape[0], ptr(tag), ptr(rtag)
+    a.d_tag_n_bonds, a.d_tag_blist, a.tag_blist_idx = ptr(tag_n_bonds), ptr(tag_blist), Index2D(n_tags, max_b)
+    a.d_n_bonds, a.d_blist, a.blist_idx, a.d_flags = ptr(n_bonds), ptr(blist), Index2D(max(N, 1), max_b), ptr(flags)
+    check(_abi.lib.hmd_update_bond_table(C.byref(a), _stream(tag)), "hmd_update_bond_table")
+    return n_bonds, blist, int(flags.item())
+
+
+def bond_forces_fene(pos, N, box, n_bonds, blist, params, compute_virial=True):
+    """params: rows of (k, r_0, epsilon_x_4, sigma_6, delta) per bond type."""
+    dev = pos.device
+    prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 5), device=dev).contiguous()
+    force = torch.full((max(N, 1), 4), float("nan"), dtype=torch.float64, device=dev)
+    virial = torch.full((6, max(N, 1)), float("nan"), dtype=torch.float64, device=dev) if compute_virial else None
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = _abi.BondArgs()
+    a.d_force, a.d_virial, a.virial_pitch, a.N, a.d_pos, a.box = ptr(force), ptr(virial), max(N, 1), N, ptr(pos), box
+    a.d_blist, a.blist_idx, a.d_n_bonds = ptr(blist), Index2D(blist.shape[1], blist.shape[0]), ptr(n_bonds)
+    a.n_bond_types, a.d_flags, a.compute_virial = prm.shape[0], ptr(flags), int(compute_virial)
+    check(_abi.lib.hmd_compute_bond_forces_fene(C.byref(a), ptr(prm), _stream(pos)), "hmd_compute_bond_forces_fene")
+    return force, virial, int(flags.item())
+
+
 def sum_net_force(forces, virials=None, net_force=None, net_virial=None, clear=True):
     dev = forces[0].device
     n = forces[0].shape[0]

@@ -316,6 +316,66 @@ int hmd_compute_pair_forces_lj(const hmd_pair_args_t* args, const hmd_lj_params_
 int hmd_compute_pair_forces_example(const hmd_pair_args_t* args, const hmd_example_params_t* d_params, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Bonds (Kremer-Grest chains: FENE + WCA).
+ * ------------------------------------------------------------------------------------------ */
+
+/* fene_params (hoomd/md/EvaluatorBondFENE.h:30-69) */
+typedef struct
+    {
+    double k;
+    double r_0;
+    double epsilon_x_4;
+    double sigma_6;
+    double delta;
+    } hmd_fene_params_t;
+
+/* Replaces gpu_update_group_table<2> (hoomd/BondedGroupData.cu:125-220): the per-particle bond table
+   in the current particle order.  Input is the same table keyed by tag, which only changes when
+   bonds are added or removed: bond k of the particle with tag t is d_tag_blist[tag_blist_idx(t, k)] =
+   (partner tag, bond type), k < d_tag_n_bonds[t], in the order the bonds were defined.  Output, for
+   the particle at index i: d_n_bonds[i] and d_blist[blist_idx(i, k)] = (partner index, bond type)
+   (hoomd/BondedGroupData.h: gpu table, group_storage<2>).  Indexers are (pitch, max bonds) with the
+   particle/tag coordinate fastest.  A partner that is not local (rtag >= n_total) sets *d_flags = 1
+   (the reference's "bond incomplete" error, hoomd/md/PotentialBond.h:228-234). */
+typedef struct
+    {
+    unsigned int N;       /* local particles */
+    unsigned int n_total; /* N + ghosts */
+    const unsigned int* d_tag;
+    const unsigned int* d_rtag;
+    const unsigned int* d_tag_n_bonds;
+    const hmd_uint2* d_tag_blist;
+    hmd_index2d_t tag_blist_idx;
+    unsigned int* d_n_bonds;
+    hmd_uint2* d_blist;
+    hmd_index2d_t blist_idx;
+    unsigned int* d_flags;
+    } hmd_bond_table_args_t;
+int hmd_update_bond_table(const hmd_bond_table_args_t* args, void* stream);
+
+/* Replaces gpu_compute_bond_forces<EvaluatorBondFENE, 2> (hoomd/md/PotentialBondGPU.cuh:97-239, driver
+   :241-330): one thread per particle walks its bond table; each end of a bond gets the force and
+   half the bond energy.  d_virial may be NULL with compute_virial == 0.  A bond stretched beyond
+   r_0 sets *d_flags = 1 and leaves that particle's outputs unwritten (the reference raises "bond out
+   of bounds" from the flag, hoomd/md/PotentialBondGPU.h:130-140). */
+typedef struct
+    {
+    hmd_scalar4* d_force;
+    double* d_virial;
+    size_t virial_pitch;
+    unsigned int N;
+    const hmd_scalar4* d_pos;
+    hmd_box_t box;
+    const hmd_uint2* d_blist;
+    hmd_index2d_t blist_idx;
+    const unsigned int* d_n_bonds;
+    unsigned int n_bond_types;
+    unsigned int* d_flags;
+    int compute_virial;
+    } hmd_bond_args_t;
+int hmd_compute_bond_forces_fene(const hmd_bond_args_t* args, const hmd_fene_params_t* d_params, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Integrator.
  * ------------------------------------------------------------------------------------------ */
 
