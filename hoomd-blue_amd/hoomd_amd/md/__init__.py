@@ -1,5 +1,5 @@
 """Molecular dynamics operations (hoomd/md/__init__.py): the short-range pair path."""
-from . import compute, methods, nlist, pair
+from . import bond, compute, methods, nlist, pair
 from .integrate import Integrator
 
-__all__ = ["Integrator", "compute", "methods", "nlist", "pair"]
+__all__ = ["Integrator", "bond", "compute", "methods", "nlist", "pair"]

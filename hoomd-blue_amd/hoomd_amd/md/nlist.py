@@ -49,9 +49,11 @@ class NeighborList:
             self._apply_exclusions()
 
     def _apply_exclusions(self):
-        # hoomd/md/NeighborList.cc:383-393: topology-derived exclusions.  This backend holds no bond
-        # topology, so 'bond' etc. resolve to nothing; 'body' turns on the body filter.
+        # hoomd/md/NeighborList.cc:383-393: topology-derived exclusions.  Bonds are the only topology
+        # this backend holds ('angle' etc. resolve to nothing); 'body' turns on the body filter.
         self._cpp_obj.clearExclusions()
+        if "bond" in self._exclusions:
+            self._cpp_obj.addExclusionsFromBonds()
         self._cpp_obj.setFilterBody("body" in self._exclusions)
 
     def add_exclusion(self, tag_i, tag_j):

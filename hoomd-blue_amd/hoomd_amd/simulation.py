@@ -25,6 +25,14 @@ class State:
         else:
             self._sysdef = decomposition._make_sysdef(snapshot, cbox, self._ndim, sim.seed)
         self._pdata = self._sysdef.getParticleData()
+        if snapshot.bonds.N or snapshot.bonds.types:
+            if decomposition is not None:
+                raise NotImplementedError("bonds under domain decomposition are outside this backend's scope")
+            self._sysdef.setBonds(*snapshot._bonds_to_args())
+
+    @property
+    def bond_types(self):
+        return list(self._sysdef.getBonds()["types"])
 
     @property
     def box(self):
@@ -43,7 +51,9 @@ class State:
         d = self._pdata.takeSnapshot()
         if self._decomposition is not None:
             d = self._decomposition._gather_snapshot(d)
-        return Snapshot._from_dict(d, self._global_box)
+        snap = Snapshot._from_dict(d, self._global_box)
+        snap._set_bonds(self._sysdef.getBonds())
+        return snap
 
     def set_snapshot(self, snapshot):
         """Overwrite the particle data; N and the type list must not change (hoomd/state.py set_snapshot)."""

@@ -54,6 +54,28 @@ class _Particles:
             getattr(self, name)[:keep] = a[:keep]
 
 
+class _Bonds:
+    """``snap.bonds.{N, types, typeid, group}`` (hoomd/snapshot.py, BondData::Snapshot)."""
+
+    def __init__(self):
+        self._N = 0
+        self.types = []
+        self.typeid = np.zeros(0, dtype=np.uint32)
+        self.group = np.zeros((0, 2), dtype=np.uint32)
+
+    @property
+    def N(self):
+        return self._N
+
+    @N.setter
+    def N(self, n):
+        n = int(n)
+        keep = min(n, self._N)
+        typeid, group = np.zeros(n, dtype=np.uint32), np.zeros((n, 2), dtype=np.uint32)
+        typeid[:keep], group[:keep] = self.typeid[:keep], self.group[:keep]
+        self._N, self.typeid, self.group = n, typeid, group
+
+
 class _Rank0:
     rank = 0
     num_ranks = 1
@@ -66,6 +88,17 @@ class Snapshot:
         self.communicator = communicator if communicator is not None else _Rank0()
         self.configuration = _Configuration()
         self.particles = _Particles()
+        self.bonds = _Bonds()
+
+    def _bonds_to_args(self):
+        b = self.bonds
+        group = np.ascontiguousarray(b.group, dtype=np.uint32)
+        typeid = np.ascontiguousarray(b.typeid, dtype=np.uint32)
+        if group.shape != (b.N, 2) or typeid.shape != (b.N,):
+            raise ValueError(f"snapshot.bonds arrays do not match N={b.N}")
+        if b.N and not b.types:
+            raise RuntimeError("snapshot.bonds.types is empty")
+        return group, typeid, list(b.types)
 
     def _to_dict(self):
         p = self.particles
@@ -88,6 +121,12 @@ class Snapshot:
         for name in s.particles._FIELDS:
             getattr(s.particles, name)[:] = d[name]
         return s
+
+    def _set_bonds(self, b):
+        self.bonds.N = int(b["N"])
+        self.bonds.types = list(b["types"])
+        self.bonds.typeid[:] = b["typeid"]
+        self.bonds.group[:] = np.asarray(b["group"]).reshape(-1, 2)
 
     def wrap(self):
         """Wrap positions into the (orthorhombic) box and update images (hoomd/snapshot.py wrap)."""

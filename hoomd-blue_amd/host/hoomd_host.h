@@ -448,6 +448,65 @@ class ParticleData
     uint64_t m_sort_count = 0;
     };
 
+// ---------------------------------------------------------------------------------------------
+// BondData: bonded pairs by particle tag and their per-particle GPU table
+// (hoomd/BondedGroupData.h, group_size 2; snapshot section hoomd/BondedGroupData.h:350-420)
+// ---------------------------------------------------------------------------------------------
+struct SnapshotBondData
+    {
+    std::vector<std::array<unsigned int, 2>> groups; //!< member tags
+    std::vector<unsigned int> type_id;
+    std::vector<std::string> type_mapping;
+    };
+
+class BondData
+    {
+    public:
+    BondData(std::shared_ptr<ParticleData> pdata, const SnapshotBondData& snap);
+    ~BondData();
+    unsigned int getNGlobal() const
+        {
+        return (unsigned int)m_snap.groups.size();
+        }
+    unsigned int getNTypes() const
+        {
+        return (unsigned int)m_snap.type_mapping.size();
+        }
+    const SnapshotBondData& getSnapshot() const
+        {
+        return m_snap;
+        }
+    //! bonds per particle (index order) and the table of (partner index, bond type); brought up to
+    //! date with the particle order on request (hoomd/BondedGroupData.cc rebuildGPUTable)
+    const unsigned int* getNBondsArray()
+        {
+        update();
+        return m_n_bonds.get();
+        }
+    const hmd_uint2* getGPUTable()
+        {
+        update();
+        return m_blist.get();
+        }
+    hmd_index2d_t getGPUTableIndexer() const
+        {
+        return m_blist_idx;
+        }
+    //! throws "bond incomplete" if the last table update met a partner that is not local
+    void checkComplete();
+
+    private:
+    void update();
+    std::shared_ptr<ParticleData> m_pdata;
+    SnapshotBondData m_snap;
+    DeviceArray<unsigned int> m_tag_n_bonds, m_n_bonds;
+    DeviceArray<hmd_uint2> m_tag_blist, m_blist;
+    hmd_index2d_t m_tag_blist_idx {0, 0}, m_blist_idx {0, 0};
+    PinnedWords m_flags;
+    bool m_dirty = true;
+    int m_sort_slot, m_maxn_slot;
+    };
+
 class SystemDefinition
     {
     public:
@@ -479,12 +538,22 @@ class SystemDefinition
         {
         m_comm = c;
         }
+    //! bonds of the system (hoomd/SystemDefinition.h getBondData); null when there are none
+    std::shared_ptr<BondData> getBondData() const
+        {
+        return m_bonds;
+        }
+    void setBondData(const SnapshotBondData& snap)
+        {
+        m_bonds = snap.groups.empty() && snap.type_mapping.empty() ? nullptr : std::make_shared<BondData>(m_pdata, snap);
+        }
 
     private:
     std::shared_ptr<ParticleData> m_pdata;
     unsigned int m_ndim;
     unsigned int m_seed;
     std::shared_ptr<Communicator> m_comm;
+    std::shared_ptr<BondData> m_bonds;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -828,6 +897,8 @@ class NeighborListGPUBinned : public Compute
     // ---- exclusions (hoomd/md/NeighborList.cc:569-1211), tag based ----
     void clearExclusions();
     void addExclusion(unsigned int tag1, unsigned int tag2);
+    //! hoomd/md/NeighborList.cc:700-720
+    void addExclusionsFromBonds();
     unsigned int getNumExclusions() const
         {
         return m_n_exclusions;
@@ -1020,6 +1091,8 @@ class ForceCompute : public Compute
     std::vector<std::array<Scalar, 4>> getForcesAndEnergies();
     std::vector<std::array<Scalar, 6>> getVirials();
     Scalar calcEnergySum();
+    //! Raise what the kernels could only flag (called with the stream idle, e.g. at the end of a run)
+    virtual void checkErrors() { }
 
     protected:
     virtual void computeForces(uint64_t timestep) = 0;
@@ -1152,6 +1225,29 @@ template<class Ev> class PotentialPairGPU : public ForceCompute
     std::shared_ptr<std::vector<Scalar>> m_r_cut_nlist;
     DeviceArray<param_type> m_d_params;
     DeviceArray<Scalar> m_d_rcutsq, m_d_ronsq;
+    };
+
+// ---------------------------------------------------------------------------------------------
+// PotentialBondGPU<EvaluatorBondFENE> (hoomd/md/PotentialBond.h, hoomd/md/PotentialBondGPU.h)
+// ---------------------------------------------------------------------------------------------
+class PotentialBondFENEGPU : public ForceCompute
+    {
+    public:
+    explicit PotentialBondFENEGPU(std::shared_ptr<SystemDefinition> sysdef);
+    //! k, r0, epsilon, sigma, delta of a bond type (hoomd/md/EvaluatorBondFENE.h:47-67)
+    void setParams(unsigned int type, Scalar k, Scalar r0, Scalar epsilon, Scalar sigma, Scalar delta);
+    std::array<Scalar, 5> getParams(unsigned int type) const;
+    void checkErrors() override;
+
+    protected:
+    void computeForces(uint64_t timestep) override;
+
+    private:
+    std::shared_ptr<BondData> m_bonds;
+    std::vector<hmd_fene_params_t> m_params;
+    DeviceArray<hmd_fene_params_t> m_d_params;
+    bool m_params_dirty = true;
+    PinnedWords m_flags;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1342,6 +1438,12 @@ class IntegratorTwoStep
     void prepRun(uint64_t timestep);
     //! run the second half step that update() left pending (it is fused with the next first half)
     void flush();
+    //! after the stream has drained: let every force raise what its kernels flagged
+    void checkForceErrors()
+        {
+        for (auto& f : m_forces)
+            f->checkErrors();
+        }
     void setDeltaT(Scalar dt);
     Scalar getDeltaT() const
         {

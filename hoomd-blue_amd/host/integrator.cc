@@ -363,6 +363,7 @@ void System::run(uint64_t nsteps)
         }
     m_integrator->flush();
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    m_integrator->checkForceErrors();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     m_last_walltime = dt;
     m_last_tps = (dt > 0 && nsteps > 0) ? double(nsteps) / dt : 0.0;

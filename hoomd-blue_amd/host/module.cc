@@ -251,7 +251,43 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("getSeed", &SystemDefinition::getSeed)
         .def("isDomainDecomposed", &SystemDefinition::isDomainDecomposed)
         .def("setCommunicator", &SystemDefinition::setCommunicator)
-        .def("getCommunicator", &SystemDefinition::getCommunicator);
+        .def("getCommunicator", &SystemDefinition::getCommunicator)
+        .def("setBonds", [](SystemDefinition& sd, py::array_t<unsigned int, py::array::c_style | py::array::forcecast> group,
+                            py::array_t<unsigned int, py::array::c_style | py::array::forcecast> typeid_, std::vector<std::string> types)
+             {
+             SnapshotBondData b;
+             const size_t n = (size_t)typeid_.size();
+             if ((size_t)group.size() != 2 * n)
+                 throw std::runtime_error("bonds.group must have shape (N, 2)");
+             b.groups.resize(n);
+             b.type_id.resize(n);
+             for (size_t i = 0; i < n; i++)
+                 {
+                 b.groups[i] = {group.data()[2 * i], group.data()[2 * i + 1]};
+                 b.type_id[i] = typeid_.data()[i];
+                 }
+             b.type_mapping = types;
+             sd.setBondData(b);
+             })
+        .def("getBonds", [](SystemDefinition& sd)
+             {
+             py::dict d;
+             auto bd = sd.getBondData();
+             const size_t n = bd ? bd->getNGlobal() : 0;
+             py::array_t<unsigned int> group({n, (size_t)2});
+             py::array_t<unsigned int> tid(n);
+             for (size_t i = 0; i < n; i++)
+                 {
+                 group.mutable_data()[2 * i] = bd->getSnapshot().groups[i][0];
+                 group.mutable_data()[2 * i + 1] = bd->getSnapshot().groups[i][1];
+                 tid.mutable_data()[i] = bd->getSnapshot().type_id[i];
+                 }
+             d["N"] = n;
+             d["group"] = group;
+             d["typeid"] = tid;
+             d["types"] = bd ? bd->getSnapshot().type_mapping : std::vector<std::string>();
+             return d;
+             });
 
     py::class_<ParticleGroup, std::shared_ptr<ParticleGroup>>(m, "ParticleGroup")
         .def(py::init<std::shared_ptr<SystemDefinition>>())
@@ -314,6 +350,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("getNumExclusions", &NeighborListGPUBinned::getNumExclusions)
         .def("resetStats", &NeighborListGPUBinned::resetStats)
         .def("addExclusion", &NeighborListGPUBinned::addExclusion)
+        .def("addExclusionsFromBonds", &NeighborListGPUBinned::addExclusionsFromBonds)
         .def("clearExclusions", &NeighborListGPUBinned::clearExclusions)
         .def("compute", &NeighborListGPUBinned::compute)
         .def("peekUpdate", &NeighborListGPUBinned::peekUpdate)
@@ -364,7 +401,31 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("calcEnergySum", &ForceCompute::calcEnergySum)
         .def("getExternalEnergy", &ForceCompute::getExternalEnergy)
         .def("getExternalVirial", &ForceCompute::getExternalVirial)
-        .def_property_readonly("force_ptr", [](ForceCompute& f) { return (uintptr_t)f.getForceArray(); });
+        .def_property_readonly("force_ptr", [](ForceCompute& f) { return (uintptr_t)f.getForceArray(); })
+        .def("checkErrors", [](ForceCompute& f)
+             {
+             hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+             f.checkErrors();
+             });
+
+    py::class_<PotentialBondFENEGPU, ForceCompute, std::shared_ptr<PotentialBondFENEGPU>>(m, "PotentialBondFENEGPU")
+        .def(py::init<std::shared_ptr<SystemDefinition>>())
+        .def("setParams", [](PotentialBondFENEGPU& self, unsigned int type, py::dict v)
+             {
+             self.setParams(type, v["k"].cast<Scalar>(), v["r0"].cast<Scalar>(), v["epsilon"].cast<Scalar>(), v["sigma"].cast<Scalar>(),
+                            v["delta"].cast<Scalar>());
+             })
+        .def("getParams", [](PotentialBondFENEGPU& self, unsigned int type)
+             {
+             const auto p = self.getParams(type);
+             py::dict v;
+             v["k"] = p[0];
+             v["r0"] = p[1];
+             v["epsilon"] = p[2];
+             v["sigma"] = p[3];
+             v["delta"] = p[4];
+             return v;
+             });
 
     export_pair<EvaluatorLJHost>(
         m, "PotentialPairLJGPU",

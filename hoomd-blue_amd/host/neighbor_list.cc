@@ -597,6 +597,16 @@ void NeighborListGPUBinned::clearExclusions()
     }
 
 // hoomd/md/NeighborList.cc:569-640: symmetric, duplicates ignored
+// hoomd/md/NeighborList.cc:700-720
+void NeighborListGPUBinned::addExclusionsFromBonds()
+    {
+    auto bonds = m_sysdef->getBondData();
+    if (!bonds)
+        return;
+    for (const auto& g : bonds->getSnapshot().groups)
+        addExclusion(g[0], g[1]);
+    }
+
 void NeighborListGPUBinned::addExclusion(unsigned int tag1, unsigned int tag2)
     {
     const unsigned int ng = m_pdata->getNGlobal();

@@ -69,3 +69,51 @@ def make_ka_simulation(hoomd, n, rho=1.2, kT=1.0, buffer=0.4, dt=0.005, seed=123
     sim.operations.integrator = hoomd.md.Integrator(dt=dt, methods=[method], forces=[lj])
     sim.operations.tuners[0].trigger = sorter_period
     return sim, cell, lj, method
+
+
+def make_kg_snapshot(hoomd, n, chain_length=32, kT=1.0, seed=1234, jitter=0.02):
+    """Kremer-Grest melt start: linear chains laid along x on an n[0] x n[1] x n[2] lattice (spacing 0.97 along the
+    chains, 1.05 across them: rho = 0.935), every chain_length consecutive sites of a row bonded (rows wrap around
+    the periodic box, so n[0] must be a multiple of chain_length)."""
+    if isinstance(n, int):
+        n = (n, n, n)
+    if n[0] % chain_length:
+        raise ValueError("n[0] must be a multiple of chain_length")
+    a = np.array([0.97, 1.05, 1.05])
+    L = np.array(n) * a
+    rng = np.random.default_rng(seed)
+    g = [(np.arange(k) + 0.5) * s - l / 2 for k, s, l in zip(n, a, L)]
+    z, y, x = np.meshgrid(g[2], g[1], g[0], indexing="ij")
+    xyz = np.stack([x.ravel(), y.ravel(), z.ravel()], 1) + rng.normal(0, jitter, (x.size, 3))
+    N = len(xyz)
+    snap = hoomd.Snapshot()
+    snap.configuration.box = [L[0], L[1], L[2], 0, 0, 0]
+    snap.particles.N = N
+    snap.particles.types = ["A"]
+    snap.particles.position[:] = xyz
+    v = rng.normal(0, np.sqrt(kT), (N, 3))
+    snap.particles.velocity[:] = v - v.mean(0)
+    idx = np.arange(N).reshape(-1, n[0])                      # rows along x
+    left = idx.reshape(-1, chain_length)[:, :-1].ravel()       # every site but the last of its chain
+    snap.bonds.N = len(left)
+    snap.bonds.types = ["polymer"]
+    snap.bonds.group[:] = np.stack([left, left + 1], 1)
+    snap.wrap()
+    return snap
+
+
+def make_kg_simulation(hoomd, n, chain_length=32, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200):
+    """WCA pair force (LJ cut at 2^(1/6), shifted) + FENE/WCA bonds (k = 30, r0 = 1.5), bonded pairs excluded from
+    the pair force: the Kremer-Grest bead-spring melt."""
+    snap = make_kg_snapshot(hoomd, n, chain_length, kT, seed)
+    sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=seed)
+    sim.create_state_from_snapshot(snap)
+    cell = hoomd.md.nlist.Cell(buffer=buffer, exclusions=("bond",))
+    wca = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.0 ** (1.0 / 6.0), mode="shift")
+    wca.params[("A", "A")] = dict(epsilon=1.0, sigma=1.0)
+    fene = hoomd.md.bond.FENEWCA()
+    fene.params["polymer"] = dict(k=30.0, r0=1.5, epsilon=1.0, sigma=1.0, delta=0.0)
+    method = hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All(), thermostat=thermostat)
+    sim.operations.integrator = hoomd.md.Integrator(dt=dt, methods=[method], forces=[wca, fene])
+    sim.operations.tuners[0].trigger = sorter_period
+    return sim, cell, wca, fene, method
