@@ -71,8 +71,9 @@ def main():
     ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpp", type=int, default=0)
-    ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka"],
-                    help="lj: the headline LJ liquid; ka: Kob-Andersen 80:20 mixture at rho 1.2 under a Bussi thermostat (side measurement)")
+    ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka", "kg"],
+                    help="lj: the headline LJ liquid; side measurements: ka = Kob-Andersen 80:20 mixture at rho 1.2 under a Bussi "
+                         "thermostat, kg = Kremer-Grest bead-spring melt (WCA + FENE bonds, chains of 32 along the lattice's x rows)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
 
@@ -108,6 +109,11 @@ def main():
     if args.workload == "ka":
         thermostat = hoomd.md.methods.thermostats.Bussi(kT=1.0)
         sim, cell, lj, method = lj_liquid.make_ka_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
+    elif args.workload == "kg":
+        if world > 1:
+            raise SystemExit("the bonded workload runs on one GPU")
+        thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.0, tau=0.5)
+        sim, cell, lj, fene, method = lj_liquid.make_kg_simulation(hoomd, n, thermostat=thermostat)
     else:
         thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
         sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
@@ -125,7 +131,7 @@ def main():
     # ---- warm-up: melt under the thermostat (all but the last 200 steps), then NVE ----
     melt = max(args.warmup - 200, 0) if args.warmup >= 400 else args.warmup // 2
     sim.run(melt)
-    if args.workload == "lj":
+    if args.workload != "ka":
         method.thermostat = None  # the Kob-Andersen case keeps its thermostat, as the reference configuration does
     sim.run(args.warmup - melt)
 
@@ -189,6 +195,9 @@ def main():
                 "workload": (f"Kob-Andersen 80:20 LJ mixture N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) "
                              "rho=1.2 kT=1.0 r_cut=2.5 sigma_ij buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume with Bussi thermostat, fp64"
                              if args.workload == "ka" else
+                             f"Kremer-Grest melt N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, chains of 32) rho=0.935 kT=1.0 WCA r_cut=2^(1/6) shifted + "
+                             "FENE k=30 r0=1.5, bond exclusions, buffer=0.4 dt=0.005, Cell nlist + ConstantVolume (NVE), fp64"
+                             if args.workload == "kg" else
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
                              "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
                 "N": N_total, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),

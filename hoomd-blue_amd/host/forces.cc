@@ -217,6 +217,15 @@ template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d
     a.threads_per_particle = m_tpp;
     if (tiles && m_tpp != 4 && m_tpp != 8 && m_tpp != 16)
         a.threads_per_particle = 0; // the tile kernel is built for 4, 8 and 16 lanes per particle
+    if (!tiles && m_tpp == 0)
+        {
+        // the reference tunes this at run time (hoomd/md/PotentialPairGPU.h:120-145); here: rows of at most 32
+        // entries (short cutoffs, e.g. WCA) are walked by 4 lanes, longer rows by 8 (measured at 11 and 84 neighbors)
+        unsigned int longest = 0;
+        for (unsigned int n : m_nlist->getNmaxPerType())
+            longest = std::max(longest, n);
+        a.threads_per_particle = longest <= 32 ? 4u : 8u;
+        }
     a.d_skip_flag = d_skip_flag;
     a.skip_value = skip_value;
     if (tiles)
