@@ -96,6 +96,7 @@ class Operations:
         self._integrator = None
         self.tuners = _TunerList([ParticleSorter()])  # hoomd/operations.py:75
         self.computes = []
+        self.writers = []  # hoomd/operations.py: objects with a trigger and _write(sim)
         self._scheduled = False
 
     @property
@@ -119,6 +120,8 @@ class Operations:
             self.integrator = op
         elif isinstance(op, ParticleSorter):
             self.tuners.append(op)
+        elif hasattr(op, "_write") and hasattr(op, "trigger"):
+            self.writers.append(op)
         else:
             self.computes.append(op)
         self._scheduled = False
@@ -206,6 +209,16 @@ class Simulation:
         if domain_decomposition is not None:
             domain_decomposition._attach(self)
 
+    def create_state_from_gsd(self, filename, frame=-1, domain_decomposition=None):
+        """hoomd/simulation.py:180-220: the state and the time step of one frame of a GSD file."""
+        if self._state is not None:
+            raise RuntimeError("Cannot initialize more than once\n")
+        from .write.gsd import read_frame
+        snapshot, step = read_frame(str(filename), int(frame))
+        if self._init_timestep == 0:
+            self._init_timestep = step
+        self.create_state_from_snapshot(snapshot, domain_decomposition)
+
     # ---- helpers used by the operations when they attach ----
     def _get_group(self, flt):
         if flt not in self._groups:
@@ -252,6 +265,30 @@ class Simulation:
             if steps:
                 raise RuntimeError("Cannot run without an integrator")
             return
-        self._cpp_sys.run(int(steps))
-        self._tps = self._cpp_sys.getLastTPS()
-        self._walltime = self._cpp_sys.getLastWalltime()
+        writers = list(self.operations.writers)
+        if not writers:
+            self._cpp_sys.run(int(steps))
+            self._tps = self._cpp_sys.getLastTPS()
+            self._walltime = self._cpp_sys.getLastWalltime()
+            return
+        # hoomd/System.cc:80-190: writers act on the state after a step, when their trigger fires at the new
+        # time step (and before the first step with write_at_start); the run is cut at those steps
+        if write_at_start:
+            for w in writers:
+                if w.trigger(self.timestep):
+                    w._write(self)
+        done, wall = 0, 0.0
+        steps = int(steps)
+        while done < steps:
+            t0 = self.timestep
+            k = next((j for j in range(1, steps - done + 1) if any(w.trigger(t0 + j) for w in writers)), steps - done)
+            self._cpp_sys.run(k)
+            wall += self._cpp_sys.getLastWalltime()
+            done += k
+            for w in writers:
+                if w.trigger(self.timestep):
+                    w._write(self)
+        for w in writers:
+            w.flush()
+        self._walltime = wall
+        self._tps = steps / wall if wall > 0 else 0.0

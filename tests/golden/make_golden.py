@@ -4,6 +4,8 @@
   reference's own header arithmetic (BoxDim.h, Index1D.h, EvaluatorPairLJ.h,
   EvaluatorPairExample.h, EvaluatorBondFENE.h) where it lies under /root/reference.  Doubles are
   C99 hex floats.
+* ref_written.gsd -- a two-frame "hoomd"-schema file written through the reference's own file library
+  (hoomd/extern/gsd.c, compiled into oracle/_ref/libgsd_ref.so), read back by tests/test_gsd.py.
 * bond_fenewca_cases.json -- the FENEWCA rows of the parameter table in the reference's
   hoomd/md/pytest/test_bond.py (two particles 0.969 apart, expected force and energy to 1e-2).
 * lj_forces_and_energies.json -- the "LJ" rows of the reference's data file
@@ -46,6 +48,39 @@ def main():
     assert len(cases) == 3
     with open(os.path.join(HERE, "bond_fenewca_cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
+
+    # a small GSD file written by the reference's library
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libgsd_ref.so"))
+    h = C.create_string_buffer(4096)
+    out_gsd = os.path.join(HERE, "ref_written.gsd")
+    assert lib.gsd_create_and_open(h, out_gsd.encode(), b"golden", b"hoomd", C.c_uint32((1 << 16) | 4), 3, 0) == 0
+
+    def put(name, a, t):
+        a = np.ascontiguousarray(a)
+        n, m = (a.shape[0], a.shape[1]) if a.ndim == 2 else (a.shape[0], 1)
+        assert lib.gsd_write_chunk(h, name.encode(), t, C.c_uint64(n), C.c_uint32(m), 0, a.ctypes.data_as(C.c_void_p)) == 0
+
+    types = np.zeros((2, 4), dtype=np.uint8)
+    types[0, :1] = list(b"A")
+    types[1, :3] = list(b"Bee")
+    btypes = np.frombuffer(b"polymer\0", dtype=np.uint8).reshape(1, 8)
+    for frame, step in enumerate((100, 200)):
+        put("configuration/step", np.array([step], dtype=np.uint64), 4)
+        put("configuration/box", np.array([10, 12, 14, 0, 0, 0], dtype=np.float32), 9)
+        put("particles/N", np.array([5], dtype=np.uint32), 3)
+        put("particles/position", np.arange(15, dtype=np.float32).reshape(5, 3) * 0.25 + frame, 9)
+        if frame == 0:
+            put("configuration/dimensions", np.array([3], dtype=np.uint8), 1)
+            put("particles/types", types, 1)
+            put("particles/typeid", np.array([0, 1, 0, 1, 1], dtype=np.uint32), 3)
+            put("bonds/N", np.array([2], dtype=np.uint32), 3)
+            put("bonds/types", btypes, 1)
+            put("bonds/typeid", np.array([0, 0], dtype=np.uint32), 3)
+            put("bonds/group", np.array([[0, 1], [1, 2]], dtype=np.uint32), 3)
+        assert lib.gsd_end_frame(h) == 0
+    assert lib.gsd_close(h) == 0
 
     shutil.copyfile(os.path.join(REF, "hoomd/md/pytest/true_pair_list.json"),
                     os.path.join(HERE, "true_pair_list.json"))
