@@ -175,12 +175,15 @@ template<class Ev> Scalar PotentialPairGPU<Ev>::getROn(unsigned int typ1, unsign
 // hoomd/md/PotentialPairGPU.h:89-160
 template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     {
-    m_spec_tstep = ~0ull;
-    m_nlist->compute(timestep); // may call launchKernel() through the speculation hook
+    // The speculation hook may already have queued this step's kernel: from inside compute() below, or,
+    // under domain decomposition, from the communicator's look at the rebuild decision before this call.
+    m_nlist->compute(timestep);
     if (m_nlist->getStorageMode() == NeighborListGPUBinned::half)
         throw std::runtime_error("PotentialPairGPU cannot handle a half neighborlist");
-    // the speculative launch stands when the list was not rebuilt at this step
-    if (!(m_spec_tstep == timestep && m_nlist->getLastBuildTimestep() != timestep))
+    // the speculative launch stands when the list was not rebuilt at this step; it is used once
+    const bool queued = m_spec_tstep == timestep && m_nlist->getLastBuildTimestep() != timestep;
+    m_spec_tstep = ~0ull;
+    if (!queued)
         launchKernel(nullptr, 0);
     computeTailCorrection();
     }
