@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka", "kg"],
                     help="lj: the headline LJ liquid; side measurements: ka = Kob-Andersen 80:20 mixture at rho 1.2 under a Bussi "
                          "thermostat, kg = Kremer-Grest bead-spring melt (WCA + FENE bonds, chains of 32 along the lattice's x rows)")
+    ap.add_argument("--time-all", action="store_true", help="time every kernel family with HIP events (perturbs the run) and print the table to stderr")
+    ap.add_argument("--cprofile", action="store_true", help="profile the host side of the timed region (rank 0, to stderr)")
+    ap.add_argument("--force-dd", action="store_true", help="run the domain-decomposition code path even on one rank (rehearsal of the RCCL calls)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
 
@@ -95,8 +98,12 @@ def main():
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     decomposition = None
     grid = grid_for(world)
-    if world > 1:
+    if world > 1 or args.force_dd:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
@@ -139,14 +146,29 @@ def main():
     cell._cpp_obj.resetStats()
     cpp.reset_kernel_timing()
     # launches predicated off by a stale neighbor list (one per rebuild step) last a few microseconds: not counted
-    cpp.enable_kernel_timing(True, "pair_force", 20.0)
+    if args.time_all:
+        cpp.enable_kernel_timing(True, "", 0.0)
+    else:
+        cpp.enable_kernel_timing(True, "pair_force", 20.0)
     barrier()
+    prof = None
+    if args.cprofile and rank == 0:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     sim.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     timing = cpp.kernel_timing()
     cpp.enable_kernel_timing(False)
+    if args.time_all and rank == 0:
+        for k, (c, ms) in sorted(timing.items(), key=lambda kv: -kv[1][1]):
+            print(f"{k:24s} launches {c:7d}  total {ms:9.2f} ms  per step {1e3 * ms / args.steps:8.2f} us", file=sys.stderr)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -213,7 +235,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if world > 1 or args.force_dd:
         dist.barrier()
         dist.destroy_process_group()
 

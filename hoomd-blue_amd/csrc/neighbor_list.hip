@@ -656,6 +656,13 @@ extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, 
     return hmd_launch_status();
     }
 
+extern "C" int hmd_publish_word(const unsigned int* d_word, unsigned long long* d_published, unsigned int stamp, void* stream)
+    {
+    HMD_REQUIRE(d_word && d_published, HMD_ERR_INVALID_ARGUMENT, "hmd_publish_word: d_word and d_published are required");
+    hipLaunchKernelGGL(nlist_publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_word, d_published, stamp);
+    return hmd_launch_status();
+    }
+
 extern "C" size_t hmd_nlist_head_list_workspace_bytes(unsigned int N)
     {
     return sizeof(unsigned long long) * (size_t)(hmd_div_up(N, HL_TILE) + 1);

@@ -198,6 +198,7 @@ _SIGNATURES = {
     "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
     "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
+    "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),
     "hmd_compute_bond_forces_fene": (C.c_int, [C.POINTER(BondArgs), vp, vp]),
     "hmd_compute_pair_forces_lj": (C.c_int, [C.POINTER(PairArgs), vp, vp]),

@@ -501,7 +501,9 @@ class Communicator(_cpp.Communicator):
         return self.exchange.any_rank(bool(local))
 
     def beginRebuildVote(self, d_flag, checkn):
-        """Device-side rebuild vote: no host round trip between the distance check and the reduction.
+        """Device-side rebuild vote: the flag word of the distance check (the number of the last check that
+        found the list stale, the same count on every rank) is MAX-reduced in place over all ranks, with no
+        host round trip between the distance check and the reduction.
         On the (common) steps where only ghost positions need refreshing the halo exchange is queued first,
         so one wait covers both and work predicated on the vote can be queued behind it."""
         ex = self.exchange
@@ -510,17 +512,19 @@ class Communicator(_cpp.Communicator):
         if self._in_communicate and not self._force_migrate and not self._ghosts_fresh:
             ex.update_ghosts()
             self._ghosts_fresh = True
-        self._vote = (self._flag_view[1] == int(checkn)).to(torch.int32)
+        word = self._flag_view[1]
         if ex._stage:  # gloo rehearsal on device memory: reduce through the host
-            v = self._vote.cpu()
+            v = word.cpu()
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.dd.group)
-            self._vote.copy_(v)
+            word.copy_(v)
         else:
-            dist.all_reduce(self._vote, op=dist.ReduceOp.MAX, group=self.dd.group)
-        return self._vote.data_ptr()
+            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.dd.group)
+        self._vote = (word, int(checkn))
+        return int(d_flag)
 
     def endRebuildVote(self):
-        return bool(self._vote.item())
+        word, checkn = self._vote
+        return int(word.item()) == checkn
 
     def communicate(self, timestep):
         ex = self.exchange

@@ -572,9 +572,11 @@ class Communicator
     //! global logical OR of a local flag (the rebuild vote, hoomd/md/NeighborListGPU.cc:84-98)
     virtual bool anyRank(bool local) = 0;
     //! The same vote without a host round trip in the middle: d_flag is the device word of the distance
-    //! check ("stale" when it equals checkn).  Queues the reduction over all ranks behind the check and
-    //! returns the address of a device word that becomes 1 when any rank is stale, 0 otherwise (0 = not
-    //! supported: fall back to anyRank).  endRebuildVote() waits for it and returns its value.
+    //! check ("stale" when it equals checkn; it only ever holds check numbers, which all ranks count alike).
+    //! Queues a MAX-reduction of that word over all ranks behind the check, in place, and returns its address:
+    //! afterwards it equals checkn on every rank iff the list of any rank is stale (0 = not supported: fall
+    //! back to anyRank).  The caller reads the word itself (hmd_publish_word); endRebuildVote() is the slow
+    //! way to the same answer.
     virtual uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn)
         {
         return 0;

@@ -231,9 +231,28 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         const uintptr_t d_vote = comm->beginRebuildVote((uintptr_t)m_flag.get(), m_checkn);
         if (d_vote)
             {
+            const unsigned int* d_word = reinterpret_cast<const unsigned int*>(d_vote);
             if (m_speculate)
-                m_speculate(timestep, reinterpret_cast<const unsigned int*>(d_vote), 1u);
-            return comm->endRebuildVote();
+                m_speculate(timestep, d_word, m_checkn);
+            // the reduced word reaches the host like the local one does: published to pinned memory, polled
+            volatile unsigned long long* hv = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 20);
+            abiCheck(hmd_publish_word(d_word, reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 20), m_checkn, nullptr),
+                     "hmd_publish_word");
+            unsigned long long v = 0;
+            for (uint64_t spins = 0;; spins++)
+                {
+                v = *hv;
+                if ((unsigned int)(v >> 32) == m_checkn)
+                    break;
+                __builtin_ia32_pause();
+                if ((spins & 0xfffff) == 0xfffff)
+                    {
+                    hipError_t q = hipStreamQuery(0);
+                    if (q != hipSuccess && q != hipErrorNotReady)
+                        hipCheck(q, "rebuild vote");
+                    }
+                }
+            return (unsigned int)v == m_checkn;
             }
         }
     // only on the consumer's own path (compute): nothing else touches the particles before the forces

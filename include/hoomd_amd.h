@@ -174,6 +174,12 @@ typedef struct
     } hmd_nlist_check_args_t;
 int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream);
 
+/* The low-latency readback on its own: queues a one-wave kernel that stores (stamp << 32 | *d_word) to
+   d_published (see hmd_nlist_check_args_t).  For a flag that changes after the check, e.g. once it has
+   been reduced over the ranks of a domain decomposition (the role of the MPI_Allreduce in
+   hoomd/md/NeighborListGPU.cc:86-98).  No counterpart kernel in the reference. */
+int hmd_publish_word(const unsigned int* d_word, unsigned long long* d_published, unsigned int stamp, void* stream);
+
 /* Replaces gpu_nlist_build_head_list (hoomd/md/NeighborListGPU.cu:415-456):
    d_head_list[i] = sum_{j<i} d_Nmax[type_j];  *d_req_size_nlist = sum over all N.
    d_workspace must hold hmd_nlist_head_list_workspace_bytes(N) bytes. */
