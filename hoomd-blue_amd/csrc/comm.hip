@@ -36,6 +36,33 @@ __global__ void __launch_bounds__(256) ghost_plan_kernel(hmd_ghost_plan_args_t a
     a.d_plan[idx] = plan & a.mask;
     }
 
+__global__ void __launch_bounds__(256) migrate_dest_kernel(hmd_migrate_dest_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool leaves = false;
+    if (idx < a.N)
+        {
+        const double4 p = hmd_ld4(a.d_pos + idx);
+        const double x[3] = {p.x, p.y, p.z};
+        unsigned int c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            {
+            const double f = HMD_SUB(x[d], a.global_lo[d]) / a.global_L[d];
+            const double w = a.decomposed[d] ? floor(f) : 0.0;
+            const double g = floor(HMD_MUL(HMD_SUB(f, w), (double)a.grid[d]));
+            const long long gi = (long long)g;
+            c[d] = (unsigned int)min(max(gi, 0ll), (long long)a.grid[d] - 1);
+            }
+        const unsigned int dest = (c[2] * a.grid[1] + c[1]) * a.grid[0] + c[0];
+        a.d_dest[idx] = (int)dest;
+        leaves = dest != a.rank;
+        }
+    const unsigned long long m = __ballot(leaves);
+    if (m && (threadIdx.x & 63) == 0)
+        atomicAdd(a.d_n_leave, (unsigned int)__popcll(m));
+    }
+
 __global__ void __launch_bounds__(256) pack_pos_kernel(hmd_pack_pos_args_t a)
     {
     const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,6 +82,19 @@ extern "C" int hmd_make_ghost_exchange_plan(const hmd_ghost_plan_args_t* args, v
     if (args->N == 0)
         return HMD_OK;
     hipLaunchKernelGGL(ghost_plan_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: args is NULL");
+    HMD_REQUIRE(args->d_pos && args->d_dest && args->d_n_leave, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: pos, dest and n_leave are required");
+    for (int d = 0; d < 3; d++)
+        HMD_REQUIRE(args->grid[d] >= 1 && args->global_L[d] > 0.0, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: empty grid or box");
+    HMD_REQUIRE(args->rank < args->grid[0] * args->grid[1] * args->grid[2], HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: rank outside the grid");
+    if (args->N == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(migrate_dest_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }
 

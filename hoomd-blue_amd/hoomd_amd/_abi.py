@@ -158,6 +158,11 @@ class GhostPlanArgs(C.Structure):
                 ("mask", u32)]
 
 
+class MigrateDestArgs(C.Structure):
+    _fields_ = [("d_pos", vp), ("N", u32), ("global_lo", f64 * 3), ("global_L", f64 * 3), ("grid", u32 * 3),
+                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("rank", u32), ("d_dest", vp), ("d_n_leave", vp)]
+
+
 class PackPosArgs(C.Structure):
     _fields_ = [("d_out", vp), ("d_pos", vp), ("d_send_idx", vp), ("d_send_shift_id", vp), ("d_shift_table", vp),
                 ("n_send", u32)]
@@ -198,6 +203,7 @@ _SIGNATURES = {
     "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
     "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
+    "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),
     "hmd_compute_bond_forces_fene": (C.c_int, [C.POINTER(BondArgs), vp, vp]),

@@ -97,6 +97,11 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def _abi():
+    from . import _abi as m
+    return m
+
+
 class PDataArrays:
     """Zero-copy torch views of the device arrays owned by the C++ ParticleData."""
 
@@ -129,6 +134,7 @@ class PDataArrays:
     n_ghosts = property(lambda self: self._p.n_ghosts)
     n_global = property(lambda self: self._p.N_global)
     max_n = property(lambda self: self._p.max_n)
+    ntypes = property(lambda self: len(self._p.types))
 
     def refresh(self):
         self._bind()
@@ -309,6 +315,9 @@ class ParticleExchange:
         self.n_migrated_out = 0
         self.n_migrated_in = 0
         self._vote = None
+        self._n_leave = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._r_ghost = None
+        self._r_ghost_value = None
 
     # ---- collectives ----
     def _a2a(self, out, inp, out_splits, in_splits):
@@ -330,21 +339,43 @@ class ParticleExchange:
         A, dd = self.arrays, self.dd
         N = A.N
         A.set_n_ghosts(0)  # ghosts are re-exchanged afterwards
-        x = A.pos[:N, :3]
-        f = (x - self.glo) / self.gL
-        wrap = torch.where(self.dec, torch.floor(f), torch.zeros_like(f))
-        c = torch.clamp(torch.floor((f - wrap) * self.gridf).to(torch.int64), min=torch.zeros_like(self.gridi), max=self.gridi - 1)
-        dest = (c[:, 2] * dd.grid[1] + c[:, 1]) * dd.grid[0] + c[:, 0]
-        leave = dest != dd.rank
-        li = torch.nonzero(leave).flatten()
+        wrap = None
+        if self.device.type == "cuda":
+            # one kernel decides every particle's owner and counts the leavers; nothing else runs when none leaves
+            dest = torch.empty(max(N, 1), dtype=torch.int32, device=self.device)[:N]
+            self._n_leave.zero_()
+            a = _abi().MigrateDestArgs()
+            a.d_pos, a.N, a.rank = A.pos.data_ptr(), N, dd.rank
+            a.global_lo[:], a.global_L[:], a.grid[:] = list(dd.glo), list(dd.gL), list(dd.grid)
+            a.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
+            a.d_dest, a.d_n_leave = dest.data_ptr(), self._n_leave.data_ptr()
+            _abi().check(_abi().lib.hmd_migrate_dest(ctypes.byref(a), None), "hmd_migrate_dest")
+            if int(self._n_leave.item()):
+                leave = dest != dd.rank
+                li = torch.nonzero(leave).flatten()
+            else:
+                leave = None
+                li = torch.zeros(0, dtype=torch.int64, device=self.device)
+        else:
+            x = A.pos[:N, :3]
+            f = (x - self.glo) / self.gL
+            wrap = torch.where(self.dec, torch.floor(f), torch.zeros_like(f))
+            c = torch.clamp(torch.floor((f - wrap) * self.gridf).to(torch.int64), min=torch.zeros_like(self.gridi), max=self.gridi - 1)
+            dest = (c[:, 2] * dd.grid[1] + c[:, 1]) * dd.grid[0] + c[:, 0]
+            leave = dest != dd.rank
+            li = torch.nonzero(leave).flatten()
         n_leave = int(li.numel())
         send_counts = [0] * dd.world
         payload = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
         if n_leave:
-            dl, order = torch.sort(dest[li], stable=True)
+            dl, order = torch.sort(dest[li].to(torch.int64), stable=True)
             li = li[order]
             send_counts = torch.bincount(dl, minlength=dd.world).tolist()
-            w = wrap[li]
+            if wrap is not None:
+                w = wrap[li]
+            else:
+                fl = (A.pos[li, :3] - self.glo) / self.gL
+                w = torch.where(self.dec, torch.floor(fl), torch.zeros_like(fl))
             p = A.pos[li].clone()
             p[:, :3] -= w * self.gL
             img = A.image[li].to(torch.int64) + w.to(torch.int64)
@@ -361,7 +392,7 @@ class ParticleExchange:
         self._a2a(incoming, payload, recv_counts, send_counts)
         if n_leave == 0 and n_recv == 0:
             return False
-        keep = torch.nonzero(~leave).flatten()
+        keep = torch.nonzero(~leave).flatten() if leave is not None else torch.arange(N, dtype=torch.int64, device=self.device)
         n_keep = int(keep.numel())
         new_n = n_keep + n_recv
         kept = {name: getattr(A, name)[keep] for name in HostArrays._PER_PARTICLE} if n_leave else None
@@ -390,12 +421,25 @@ class ParticleExchange:
         for a in range(3):
             if dd.decomposed[a] and width[a] <= 2.0 * r_ghost:
                 raise RuntimeError("Simulation box too small for domain decomposition: a sub-box must be wider than twice the ghost layer")
-        x = A.pos[:N, :3]
-        f = (x - self.lo) / (self.hi - self.lo)
-        g = r_ghost / (self.hi - self.lo)
-        bits = torch.tensor([[1, 4, 16], [2, 8, 32]], dtype=torch.int32, device=self.device)
-        decm = self.dec.to(torch.int32)
-        plan = (((f >= (1.0 - g)).to(torch.int32) * bits[0] + (f < g).to(torch.int32) * bits[1]) * decm).sum(dim=1, dtype=torch.int32)
+        if self.device.type == "cuda":
+            plan = torch.empty(max(N, 1), dtype=torch.int32, device=self.device)[:N]
+            ntypes = max(int(getattr(A, "ntypes", 1)), 1)
+            if self._r_ghost is None or self._r_ghost.numel() != ntypes or float(self._r_ghost_value) != float(r_ghost):
+                self._r_ghost = torch.full((ntypes,), float(r_ghost), dtype=torch.float64, device=self.device)
+                self._r_ghost_value = float(r_ghost)
+            a = _abi().GhostPlanArgs()
+            a.d_plan, a.d_pos, a.N = plan.data_ptr(), A.pos.data_ptr(), N
+            a.box = _abi().Box.from_lo_hi(list(dd.lo), list(dd.hi))
+            a.d_r_ghost, a.ntypes = self._r_ghost.data_ptr(), ntypes
+            a.mask = sum(3 << (2 * ax) for ax in range(3) if dd.decomposed[ax])
+            _abi().check(_abi().lib.hmd_make_ghost_exchange_plan(ctypes.byref(a), None), "hmd_make_ghost_exchange_plan")
+        else:
+            x = A.pos[:N, :3]
+            f = (x - self.lo) / (self.hi - self.lo)
+            g = r_ghost / (self.hi - self.lo)
+            bits = torch.tensor([[1, 4, 16], [2, 8, 32]], dtype=torch.int32, device=self.device)
+            decm = self.dec.to(torch.int32)
+            plan = (((f >= (1.0 - g)).to(torch.int32) * bits[0] + (f < g).to(torch.int32) * bits[1]) * decm).sum(dim=1, dtype=torch.int32)
         b = torch.nonzero(plan).flatten()
         ndir = len(self.dir_dest)
         if ndir and b.numel():
@@ -427,7 +471,10 @@ class ParticleExchange:
         self.update_ghosts()
         A.rtag.fill_(NOT_LOCAL)
         n_all = N + n_ghost
-        A.rtag[A.tag[:n_all].to(torch.int64)] = torch.arange(n_all, dtype=torch.int32, device=self.device)
+        if self.device.type == "cuda":
+            _abi().check(_abi().lib.hmd_build_rtag(A.rtag.data_ptr(), A.tag.data_ptr(), n_all, None), "hmd_build_rtag")
+        else:
+            A.rtag[A.tag[:n_all].to(torch.int64)] = torch.arange(n_all, dtype=torch.int32, device=self.device)
 
     def pack(self):
         A = self.arrays

@@ -555,6 +555,26 @@ typedef struct
     } hmd_pack_pos_args_t;
 int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* stream);
 
+/* Owner rank of every owned particle after a move (the decision of gpu_stage_particles /
+   gpu_select_particle_migrate, hoomd/CommunicatorGPU.cu:60-170, for a regular grid of domains with
+   rank = (k * grid[1] + j) * grid[0] + i): fractional position in the global box, wrapped along
+   decomposed directions, cut into grid cells.  d_dest[i] = owner; *d_n_leave counts particles whose
+   owner is not `rank` (the caller zeroes it). */
+typedef struct
+    {
+    const hmd_scalar4* d_pos;
+    unsigned int N;
+    double global_lo[3];
+    double global_L[3];
+    unsigned int grid[3];
+    unsigned char decomposed[3];
+    unsigned char pad_;
+    unsigned int rank;
+    int* d_dest;
+    unsigned int* d_n_leave;
+    } hmd_migrate_dest_args_t;
+int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Tile path: the same neighbor list and pair forces, laid out for LDS instead of L1 gathers.
  * No single reference driver corresponds to these; together they stand in for
