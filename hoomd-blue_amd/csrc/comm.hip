@@ -85,6 +85,62 @@ extern "C" int hmd_make_ghost_exchange_plan(const hmd_ghost_plan_args_t* args, v
     return hmd_launch_status();
     }
 
+__global__ void __launch_bounds__(256) pack_vote_kernel(hmd_pack_vote_args_t a)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < a.pack.n_send)
+        {
+        const double4 p = hmd_ld4(a.pack.d_pos + a.pack.d_send_idx[k]);
+        const hmd_scalar3 sh = a.pack.d_shift_table[a.pack.d_send_shift_id[k]];
+        hmd_st4(a.pack.d_out + a.d_out_row[k], HMD_ADD(p.x, sh.x), HMD_ADD(p.y, sh.y), HMD_ADD(p.z, sh.z), p.w);
+        }
+    else if (k < a.pack.n_send + a.n_flag_rows)
+        {
+        const double w = hmd_uint_as_double(*a.d_flag_word);
+        hmd_st4(a.pack.d_out + a.d_flag_rows[k - a.pack.n_send], w, 0.0, 0.0, 0.0);
+        }
+    }
+
+__global__ void __launch_bounds__(256) unpack_vote_kernel(hmd_unpack_vote_args_t a)
+    {
+    const unsigned int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rows)
+        return;
+    const double4 p = hmd_ld4(a.d_in + r);
+    const int m = a.d_map[r];
+    if (m >= 0)
+        hmd_st4(a.d_ghost_pos + m, p.x, p.y, p.z, p.w);
+    else
+        atomicMax(a.d_flag_word, hmd_double_as_uint(p.x));
+    }
+
+extern "C" int hmd_pack_ghost_positions_vote(const hmd_pack_vote_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_positions_vote: args is NULL");
+    const hmd_pack_pos_args_t& p = args->pack;
+    HMD_REQUIRE(p.d_out && p.d_pos && p.d_shift_table, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_positions_vote: out, pos and shift_table are required");
+    HMD_REQUIRE(p.n_send == 0 || (p.d_send_idx && p.d_send_shift_id && args->d_out_row), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_positions_vote: send_idx, send_shift_id and out_row are required");
+    HMD_REQUIRE(args->n_flag_rows == 0 || (args->d_flag_word && args->d_flag_rows), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_positions_vote: flag_word and flag_rows are required");
+    const unsigned int n = p.n_send + args->n_flag_rows;
+    if (n == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(pack_vote_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_unpack_ghost_positions(const hmd_unpack_vote_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_unpack_ghost_positions: args is NULL");
+    if (args->n_rows == 0)
+        return HMD_OK;
+    HMD_REQUIRE(args->d_in && args->d_map && args->d_ghost_pos && args->d_flag_word, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_unpack_ghost_positions: in, map, ghost_pos and flag_word are required");
+    hipLaunchKernelGGL(unpack_vote_kernel, dim3(hmd_div_up(args->n_rows, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
 extern "C" int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* stream)
     {
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: args is NULL");

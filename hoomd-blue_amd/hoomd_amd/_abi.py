@@ -168,6 +168,14 @@ class PackPosArgs(C.Structure):
                 ("n_send", u32)]
 
 
+class PackVoteArgs(C.Structure):
+    _fields_ = [("pack", PackPosArgs), ("d_out_row", vp), ("d_flag_word", vp), ("d_flag_rows", vp), ("n_flag_rows", u32)]
+
+
+class UnpackVoteArgs(C.Structure):
+    _fields_ = [("d_in", vp), ("d_map", vp), ("n_rows", u32), ("d_ghost_pos", vp), ("d_flag_word", vp)]
+
+
 class FusedStepArgs(C.Structure):
     _fields_ = [("two", StepTwoArgs), ("one", StepOneArgs), ("check", NlistCheckArgs), ("d_slot_of", vp), ("d_cpos", vp)]
 
@@ -203,6 +211,8 @@ _SIGNATURES = {
     "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
     "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
+    "hmd_pack_ghost_positions_vote": (C.c_int, [C.POINTER(PackVoteArgs), vp]),
+    "hmd_unpack_ghost_positions": (C.c_int, [C.POINTER(UnpackVoteArgs), vp]),
     "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),

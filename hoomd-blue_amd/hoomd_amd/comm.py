@@ -16,6 +16,7 @@ j<-i for the particles it owns.
 """
 import ctypes
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -318,6 +319,10 @@ class ParticleExchange:
         self._n_leave = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._r_ghost = None
         self._r_ghost_value = None
+        self.vote_plan = None
+        self._vote_out = None
+        self._vote_in = None
+        self.n_vote_exchanges = 0
 
     # ---- collectives ----
     def _a2a(self, out, inp, out_splits, in_splits):
@@ -469,12 +474,68 @@ class ParticleExchange:
         A.diameter[s] = 1.0
         A.image[s] = 0
         self.update_ghosts()
+        self._build_vote_plan(n_ghost)
         A.rtag.fill_(NOT_LOCAL)
         n_all = N + n_ghost
         if self.device.type == "cuda":
             _abi().check(_abi().lib.hmd_build_rtag(A.rtag.data_ptr(), A.tag.data_ptr(), n_all, None), "hmd_build_rtag")
         else:
             A.rtag[A.tag[:n_all].to(torch.int64)] = torch.arange(n_all, dtype=torch.int32, device=self.device)
+
+    def _build_vote_plan(self, n_ghost):
+        """Row maps for the halo exchange that also carries the rebuild vote: every message gets one extra row.
+        Only when this rank exchanges ghosts with every other rank (then the maximum over the received rows and
+        the own flag is the maximum over all ranks) and the arrays are on the GPU."""
+        dd = self.dd
+        self.vote_plan = None
+        peers = [r for r in range(dd.world) if r != dd.rank]
+        if self.device.type != "cuda" or not peers or sorted(set(self.dir_dest)) != peers:
+            return
+        send, recv = self.send_splits, self.recv_splits
+        aug_send = [send[r] + (r != dd.rank) for r in range(dd.world)]
+        aug_recv = [recv[r] + (r != dd.rank) for r in range(dd.world)]
+        out_row, flag_rows, in_map = [], [], []
+        off = 0
+        for r in range(dd.world):
+            out_row.append(torch.arange(off, off + send[r], dtype=torch.int32))
+            if r != dd.rank:
+                flag_rows.append(off + send[r])
+            off += aug_send[r]
+        ghost = 0
+        for r in range(dd.world):
+            in_map.append(torch.arange(ghost, ghost + recv[r], dtype=torch.int32))
+            if r != dd.rank:
+                in_map.append(torch.full((1,), -1, dtype=torch.int32))
+            ghost += recv[r]
+        assert ghost == n_ghost
+        dev = self.device
+        self.vote_plan = dict(
+            aug_send=aug_send, aug_recv=aug_recv, n_out=sum(aug_send), n_in=sum(aug_recv),
+            out_row=torch.cat(out_row).to(dev), flag_rows=torch.tensor(flag_rows, dtype=torch.int32, device=dev),
+            in_map=torch.cat(in_map).to(dev))
+        need_out, need_in = sum(aug_send), sum(aug_recv)
+        if self._vote_out is None or self._vote_out.shape[0] < need_out:
+            self._vote_out = torch.empty((int(need_out * 1.25) + 64, 4), dtype=torch.float64, device=dev)
+        if self._vote_in is None or self._vote_in.shape[0] < need_in:
+            self._vote_in = torch.empty((int(need_in * 1.25) + 64, 4), dtype=torch.float64, device=dev)
+
+    def update_ghosts_with_vote(self, d_flag):
+        """Ghost positions and the rebuild vote in one exchange (see _build_vote_plan); afterwards the word at
+        d_flag holds the maximum of the flag words of all ranks."""
+        A, vp, m = self.arrays, self.vote_plan, _abi()
+        self.n_vote_exchanges += 1
+        a = m.PackVoteArgs()
+        a.pack.d_out, a.pack.d_pos = self._vote_out.data_ptr(), A.pos.data_ptr()
+        a.pack.d_send_idx, a.pack.d_send_shift_id = self.send_idx32.data_ptr(), self.send_dir.data_ptr()
+        a.pack.d_shift_table, a.pack.n_send = self.shift_table.data_ptr(), int(self.send_idx32.numel())
+        a.d_out_row, a.d_flag_word = vp["out_row"].data_ptr(), d_flag
+        a.d_flag_rows, a.n_flag_rows = vp["flag_rows"].data_ptr(), int(vp["flag_rows"].numel())
+        m.check(m.lib.hmd_pack_ghost_positions_vote(ctypes.byref(a), None), "hmd_pack_ghost_positions_vote")
+        self._a2a(self._vote_in[:vp["n_in"]], self._vote_out[:vp["n_out"]], vp["aug_recv"], vp["aug_send"])
+        u = m.UnpackVoteArgs()
+        u.d_in, u.d_map, u.n_rows = self._vote_in.data_ptr(), vp["in_map"].data_ptr(), vp["n_in"]
+        u.d_ghost_pos, u.d_flag_word = A.pos.data_ptr() + 32 * A.N, d_flag
+        m.check(m.lib.hmd_unpack_ghost_positions(ctypes.byref(u), None), "hmd_unpack_ghost_positions")
 
     def pack(self):
         A = self.arrays
@@ -514,6 +575,7 @@ class Communicator(_cpp.Communicator):
         self._vote = None
         self._in_communicate = False
         self._ghosts_fresh = False
+        self.use_vote_rows = os.environ.get("HOOMD_AMD_VOTE_ROWS", "1") != "0"
         self.exchange = ParticleExchange(decomposition, PDataArrays(self.pdata), pack_fn=self._pack_kernel)
 
     def _pack_kernel(self, ex):
@@ -556,10 +618,14 @@ class Communicator(_cpp.Communicator):
         ex = self.exchange
         if self._flag_view is None or self._flag_view[0] != d_flag:
             self._flag_view = (d_flag, torch.as_tensor(_DevMem(d_flag, (1,), "<i4"), device=ex.device))
-        if self._in_communicate and not self._force_migrate and not self._ghosts_fresh:
-            ex.update_ghosts()
-            self._ghosts_fresh = True
         word = self._flag_view[1]
+        if self._in_communicate and not self._force_migrate and not self._ghosts_fresh:
+            self._ghosts_fresh = True
+            if ex.vote_plan is not None and self.use_vote_rows:
+                ex.update_ghosts_with_vote(int(d_flag))
+                self._vote = (word, int(checkn))
+                return int(d_flag)
+            ex.update_ghosts()
         if ex._stage:  # gloo rehearsal on device memory: reduce through the host
             v = word.cpu()
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.dd.group)

@@ -555,6 +555,32 @@ typedef struct
     } hmd_pack_pos_args_t;
 int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* stream);
 
+/* The same pack with the rebuild vote riding along: entry k goes to row d_out_row[k] of d_out, and row
+   d_flag_rows[j] (one per destination rank, j < n_flag_rows) receives *d_flag_word in the low 32 bits of
+   its first component.  hmd_unpack_ghost_positions is the receiving side: row r of d_in is copied to
+   d_ghost_pos[d_map[r]] when d_map[r] >= 0, and is a vote row otherwise: *d_flag_word becomes the maximum
+   of itself and the row's word.  When every rank exchanges ghosts with every other rank this replaces the
+   separate reduction of the vote (MPI_Allreduce in hoomd/md/NeighborListGPU.cc:86-98) by the halo
+   exchange that happens anyway.  No counterpart kernels in the reference. */
+typedef struct
+    {
+    hmd_pack_pos_args_t pack;
+    const unsigned int* d_out_row;
+    const unsigned int* d_flag_word;
+    const unsigned int* d_flag_rows;
+    unsigned int n_flag_rows;
+    } hmd_pack_vote_args_t;
+int hmd_pack_ghost_positions_vote(const hmd_pack_vote_args_t* args, void* stream);
+typedef struct
+    {
+    const hmd_scalar4* d_in;
+    const int* d_map;
+    unsigned int n_rows;
+    hmd_scalar4* d_ghost_pos;
+    unsigned int* d_flag_word;
+    } hmd_unpack_vote_args_t;
+int hmd_unpack_ghost_positions(const hmd_unpack_vote_args_t* args, void* stream);
+
 /* Owner rank of every owned particle after a move (the decision of gpu_stage_particles /
    gpu_select_particle_migrate, hoomd/CommunicatorGPU.cu:60-170, for a regular grid of domains with
    rank = (k * grid[1] + j) * grid[0] + i): fractional position in the global box, wrapped along

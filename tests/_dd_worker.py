@@ -69,7 +69,7 @@ def main():
     stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds))
     if dd is not None:
         ex = dd.communicator.exchange
-        stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in))
+        stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges))
         allstats = [None] * world
         dist.all_gather_object(allstats, stats)
     else:
@@ -77,7 +77,8 @@ def main():
     if rank == 0:
         np.savez(out, position=s.particles.position, velocity=s.particles.velocity, image=s.particles.image, e0=e0, e1=e1,
                  dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
-                 builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats])
+                 builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats],
+                 vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats])
     if dd is not None:
         dist.barrier()
         dist.destroy_process_group()
