@@ -599,3 +599,64 @@ def test_ghost_plan_and_pack(K, A):
     exp = pos[s].copy()
     exp[:, :3] += table[sid]
     assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_migrate_dest_and_vote_rows(K, A):
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    glo, gL, grid, dec, rank = np.array([-6.0, -7.0, -8.0]), np.array([12.0, 14.0, 16.0]), (2, 1, 3), (1, 0, 1), 4
+    N = 5000
+    # some particles outside the global box along the decomposed directions (they wrap), none along y
+    xyz = glo + rng.random((N, 3)) * gL
+    xyz[:200, 0] += gL[0] * rng.choice([-1, 1], 200) * 0.3
+    xyz[200:400, 2] -= gL[2] * 0.2
+    pos = torch.from_numpy(orc.pack_pos(xyz, np.zeros(N, dtype=int))).cuda()
+    dest = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    n_leave = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a = A.MigrateDestArgs()
+    a.d_pos, a.N, a.rank = pos.data_ptr(), N, rank
+    a.global_lo[:], a.global_L[:], a.grid[:], a.decomposed[:] = list(glo), list(gL), list(grid), list(dec)
+    a.d_dest, a.d_n_leave = dest.data_ptr(), n_leave.data_ptr()
+    A.check(A.lib.hmd_migrate_dest(C.byref(a), None), "hmd_migrate_dest")
+    f = (xyz - glo) / gL
+    w = np.where(np.array(dec, dtype=bool), np.floor(f), 0.0)
+    c = np.clip(np.floor((f - w) * np.array(grid)).astype(np.int64), 0, np.array(grid) - 1)
+    want = (c[:, 2] * grid[1] + c[:, 1]) * grid[0] + c[:, 0]
+    assert np.array_equal(dest.cpu().numpy(), want)
+    assert int(n_leave.item()) == int((want != rank).sum())
+    assert A.lib.hmd_migrate_dest(None, None) == A.ERR_INVALID_ARGUMENT
+
+    # pack with vote rows, then unpack: positions land where the map says, the flag becomes the maximum
+    n_send, n_flag = 700, 3
+    send = torch.from_numpy(rng.integers(0, N, n_send).astype(np.int32)).cuda()
+    sid = torch.from_numpy(rng.integers(0, 27, n_send).astype(np.uint8)).cuda()
+    table = torch.from_numpy(rng.normal(size=(27, 3))).cuda()
+    rows = rng.permutation(n_send + n_flag)
+    out_row = torch.from_numpy(rows[:n_send].astype(np.int32)).cuda()
+    flag_rows = torch.from_numpy(rows[n_send:].astype(np.int32)).cuda()
+    flag = torch.tensor([41], dtype=torch.int32, device="cuda")
+    buf = torch.full((n_send + n_flag, 4), float("nan"), dtype=torch.float64, device="cuda")
+    p = A.PackVoteArgs()
+    p.pack.d_out, p.pack.d_pos, p.pack.d_send_idx, p.pack.d_send_shift_id = buf.data_ptr(), pos.data_ptr(), send.data_ptr(), sid.data_ptr()
+    p.pack.d_shift_table, p.pack.n_send = table.data_ptr(), n_send
+    p.d_out_row, p.d_flag_word, p.d_flag_rows, p.n_flag_rows = out_row.data_ptr(), flag.data_ptr(), flag_rows.data_ptr(), n_flag
+    A.check(A.lib.hmd_pack_ghost_positions_vote(C.byref(p), None), "hmd_pack_ghost_positions_vote")
+    exp = pos[send.long()].clone()
+    exp[:, :3] += table[sid.long()]
+    assert torch.equal(buf[out_row.long()], exp)
+    assert torch.all(buf[flag_rows.long(), 0].view(torch.int64) & 0xFFFFFFFF == 41)
+    # a "received" buffer: the same rows, two of the flag rows carrying other ranks' words (one larger)
+    buf[flag_rows.long()[0], 0] = torch.tensor([57], dtype=torch.int64, device="cuda").view(torch.float64)[0]
+    buf[flag_rows.long()[1], 0] = torch.tensor([12], dtype=torch.int64, device="cuda").view(torch.float64)[0]
+    in_map = torch.full((n_send + n_flag,), -1, dtype=torch.int32, device="cuda")
+    in_map[out_row.long()] = torch.arange(n_send, dtype=torch.int32, device="cuda")
+    ghost = torch.zeros((n_send, 4), dtype=torch.float64, device="cuda")
+    u = A.UnpackVoteArgs()
+    u.d_in, u.d_map, u.n_rows, u.d_ghost_pos, u.d_flag_word = buf.data_ptr(), in_map.data_ptr(), n_send + n_flag, ghost.data_ptr(), flag.data_ptr()
+    A.check(A.lib.hmd_unpack_ghost_positions(C.byref(u), None), "hmd_unpack_ghost_positions")
+    assert torch.equal(ghost, exp) and int(flag.item()) == 57
+    # publish: stamp and word arrive together in pinned memory
+    pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
+    A.check(A.lib.hmd_publish_word(flag.data_ptr(), pinned.data_ptr(), 9, None), "hmd_publish_word")
+    torch.cuda.synchronize()
+    assert int(pinned.item()) == (9 << 32) | 57
