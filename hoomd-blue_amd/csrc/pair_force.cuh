@@ -195,8 +195,15 @@ template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE, b
 __global__ void __launch_bounds__(PF_BLOCK) pair_force_kernel(hmd_pair_args_t a, const typename Ev::param_type* d_params)
     {
     typedef typename Ev::param_type param_t;
-    if (a.d_skip_flag && *a.d_skip_flag == a.skip_value)
-        return;
+    if (a.d_skip_flag)
+        {
+        const unsigned int word = *a.d_skip_flag;
+        if (a.d_published && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (word == a.skip_value)
+            return;
+        }
     extern __shared__ __align__(16) unsigned char s_raw[];
     const unsigned int np = a.ntypes * a.ntypes;
     param_t* s_params = reinterpret_cast<param_t*>(s_raw);

@@ -52,8 +52,15 @@ __global__ void __launch_bounds__(PFT_THREADS)
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
     {
     typedef typename Ev::param_type param_t;
-    if (a.d_skip_flag && *a.d_skip_flag == a.skip_value)
-        return;
+    if (a.d_skip_flag)
+        {
+        const unsigned int word = *a.d_skip_flag;
+        if (a.d_published && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (word == a.skip_value)
+            return;
+        }
     // All LDS of this kernel is dynamic and the tile comes first, so that the tile starts at LDS
     // address 0 and 8 * (row entry) is the address of a neighbor's x without adding a base.
     extern __shared__ __align__(16) unsigned char s_dyn[];

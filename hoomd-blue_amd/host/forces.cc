@@ -118,10 +118,11 @@ PotentialPairGPU<Ev>::PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef,
     m_nlist->addRCutMatrix(m_r_cut_nlist); // hoomd/md/PotentialPair.h:369-371
     // queue the force kernel behind the distance check, predicated on "list still valid": on the steps
     // without a rebuild (most of them) the GPU does not idle while the host reads the check's result
-    m_nlist->setSpeculationHook([this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale)
+    m_nlist->setSpeculationHook([this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale, unsigned long long* d_published,
+                                       unsigned int stamp)
                                 {
-                                launchKernel(d_flag, stale);
                                 m_spec_tstep = timestep;
+                                return launchKernel(d_flag, stale, d_published, stamp);
                                 });
     m_d_params.resize(np);
     m_d_rcutsq.resize(np);
@@ -188,7 +189,8 @@ template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     computeTailCorrection();
     }
 
-template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value)
+template<class Ev>
+bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published, unsigned int stamp)
     {
     if (m_tables_dirty)
         {
@@ -231,6 +233,8 @@ template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d
         }
     a.d_skip_flag = d_skip_flag;
     a.skip_value = skip_value;
+    a.d_published = d_published;
+    a.publish_stamp = stamp;
     if (tiles)
         m_nlist->refreshTilePositions();
     ScopedKernelTimer t("pair_force");
@@ -241,6 +245,7 @@ template<class Ev> void PotentialPairGPU<Ev>::launchKernel(const unsigned int* d
         }
     else
         abiCheck(Ev::launch(&a, m_d_params.get(), nullptr), "gpu_compute_pair_forces");
+    return a.N != 0; // the drivers launch nothing for an empty system
     }
 
 // hoomd/md/PotentialPair.h:255-341 (single rank: the per-type counts come from the type ids)

@@ -954,7 +954,9 @@ class NeighborListGPUBinned : public Compute
     //! Called from compute() right after a distance check has been queued and before the host waits for
     //! its result, with the device flag and the value it takes when the list is stale: a consumer may
     //! queue work that is only valid for a fresh list, predicated on the flag.
-    typedef std::function<void(uint64_t, const unsigned int*, unsigned int)> SpeculationHook;
+    //! (time step, device word, value that means "stale", where to publish the word for the host, stamp):
+    //! queues the consumer's kernel predicated on the word; true when a kernel that publishes was queued
+    typedef std::function<bool(uint64_t, const unsigned int*, unsigned int, unsigned long long*, unsigned int)> SpeculationHook;
     void setSpeculationHook(SpeculationHook h)
         {
         m_speculate = h;
@@ -1214,7 +1216,7 @@ template<class Ev> class PotentialPairGPU : public ForceCompute
 
     protected:
     void computeForces(uint64_t timestep) override;
-    void launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value);
+    bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0);
     void computeTailCorrection();
     uint64_t m_spec_tstep = ~0ull; // time step whose force kernel was queued speculatively
     std::shared_ptr<NeighborListGPUBinned> m_nlist;

@@ -178,9 +178,10 @@ void NeighborListGPUBinned::fillCheckArgs(hmd_nlist_check_args_t& a)
     a.r_buff = m_r_buff;
     a.ntypes = m_pdata->getNTypes();
     a.checkn = ++m_checkn;
-    // the flag comes back through pinned memory that the host polls: no stream synchronisation,
-    // the GPU idles only for the PCIe write plus the launch of the next kernel
-    a.d_published = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
+    // The flag comes back through pinned memory that the host polls: no stream synchronisation.  Not from
+    // the check itself: whoever consumes the check publishes (the predicated force kernel as its first
+    // act, or hmd_publish_word), which saves a launch per step.
+    a.d_published = nullptr;
     a.stamp = m_checkn;
     }
 
@@ -232,12 +233,11 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         if (d_vote)
             {
             const unsigned int* d_word = reinterpret_cast<const unsigned int*>(d_vote);
-            if (m_speculate)
-                m_speculate(timestep, d_word, m_checkn);
             // the reduced word reaches the host like the local one does: published to pinned memory, polled
             volatile unsigned long long* hv = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 20);
-            abiCheck(hmd_publish_word(d_word, reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 20), m_checkn, nullptr),
-                     "hmd_publish_word");
+            unsigned long long* d_pub = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 20);
+            if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn)))
+                abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, nullptr), "hmd_publish_word");
             unsigned long long v = 0;
             for (uint64_t spins = 0;; spins++)
                 {
@@ -255,10 +255,17 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
             return (unsigned int)v == m_checkn;
             }
         }
-    // only on the consumer's own path (compute): nothing else touches the particles before the forces
-    else if (m_speculate && m_in_compute)
-        m_speculate(timestep, m_flag.get(), m_checkn);
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
+    if (!m_sysdef->isDomainDecomposed())
+        {
+        unsigned long long* d_pub = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
+        // only on the consumer's own path (compute): nothing else touches the particles before the forces
+        if (!(m_speculate && m_in_compute && m_speculate(timestep, m_flag.get(), m_checkn, d_pub, m_checkn)))
+            abiCheck(hmd_publish_word(m_flag.get(), d_pub, m_checkn, nullptr), "hmd_publish_word");
+        }
+    else
+        abiCheck(hmd_publish_word(m_flag.get(), reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16), m_checkn, nullptr),
+                 "hmd_publish_word");
     unsigned long long v = 0;
     for (uint64_t spins = 0;; spins++)
         {

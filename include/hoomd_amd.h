@@ -303,6 +303,10 @@ typedef struct
        rebuild. */
     const unsigned int* d_skip_flag;
     unsigned int skip_value;
+    /* Optional, with d_skip_flag: the kernel also hands the word to the host, storing
+       (publish_stamp << 32 | *d_skip_flag) to d_published as hmd_publish_word would, before anything else. */
+    unsigned int publish_stamp;
+    unsigned long long* d_published;
     } hmd_pair_args_t;
 
 /* EvaluatorPairLJ::param_type (hoomd/md/EvaluatorPairLJ.h:99-155) */
