@@ -656,6 +656,21 @@ extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, 
     return hmd_launch_status();
     }
 
+__global__ void publish_words_kernel(const unsigned int* d_words, unsigned int n, unsigned long long* d_published, unsigned int stamp)
+    {
+    if (threadIdx.x < n)
+        __hip_atomic_store(d_published + threadIdx.x, ((unsigned long long)stamp << 32) | (unsigned long long)d_words[threadIdx.x], __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+extern "C" int hmd_publish_words(const unsigned int* d_words, unsigned int n, unsigned long long* d_published, unsigned int stamp, void* stream)
+    {
+    HMD_REQUIRE(d_words && d_published, HMD_ERR_INVALID_ARGUMENT, "hmd_publish_words: d_words and d_published are required");
+    HMD_REQUIRE(n >= 1 && n <= 64, HMD_ERR_INVALID_ARGUMENT, "hmd_publish_words: n must be in [1, 64]");
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_words, n, d_published, stamp);
+    return hmd_launch_status();
+    }
+
 extern "C" int hmd_publish_word(const unsigned int* d_word, unsigned long long* d_published, unsigned int stamp, void* stream)
     {
     HMD_REQUIRE(d_word && d_published, HMD_ERR_INVALID_ARGUMENT, "hmd_publish_word: d_word and d_published are required");

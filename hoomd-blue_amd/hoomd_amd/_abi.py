@@ -215,6 +215,7 @@ _SIGNATURES = {
     "hmd_unpack_ghost_positions": (C.c_int, [C.POINTER(UnpackVoteArgs), vp]),
     "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
+    "hmd_publish_words": (C.c_int, [vp, u32, vp, u32, vp]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),
     "hmd_compute_bond_forces_fene": (C.c_int, [C.POINTER(BondArgs), vp, vp]),
     "hmd_compute_pair_forces_lj": (C.c_int, [C.POINTER(PairArgs), vp, vp]),

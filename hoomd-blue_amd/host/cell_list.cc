@@ -163,9 +163,8 @@ void CellListGPU::computeCellList()
 // hoomd/CellList.cc:549-607
 bool CellListGPU::checkConditions()
     {
-    unsigned int* h = m_h_cond.get();
-    hipCheck(hipMemcpyAsync(h, m_conditions.get(), sizeof(hmd_uint3), hipMemcpyDeviceToHost, 0), "conditions D2H");
-    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    unsigned int h[3];
+    m_readback.read(reinterpret_cast<const unsigned int*>(m_conditions.get()), 3, h, "cell list conditions");
     bool result = false;
     if (h[0] > m_Nmax)
         {

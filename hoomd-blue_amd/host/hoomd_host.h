@@ -140,6 +140,20 @@ class PinnedWords
     unsigned int* m_d = nullptr;
     };
 
+//! Reads a few device words without a stream synchronisation: a one-wave kernel queued behind the producer
+//! stores them, stamped, to mapped pinned memory that the host polls (hmd_publish_words).
+class WordReadback
+    {
+    public:
+    WordReadback() : m_pinned(128) { }
+    //! blocks until the words have arrived; n <= 64
+    void read(const unsigned int* d_words, unsigned int n, unsigned int* out, const char* what);
+
+    private:
+    PinnedWords m_pinned; // 64 slots of 8 bytes
+    unsigned int m_stamp = 0;
+    };
+
 // ---------------------------------------------------------------------------------------------
 // signals (role of Nano::Signal, used for particle-sort / box-change / r_cut-change notifications)
 // ---------------------------------------------------------------------------------------------
@@ -781,6 +795,7 @@ class CellListGPU : public Compute
 
     Scalar m_nominal_width = 0;
     unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0, m_nmax_headroom = 0;
+    WordReadback m_readback;
     std::array<unsigned int, 3> m_dim {{0, 0, 0}};
     Scalar3 m_ghost_width {0, 0, 0};
     bool m_params_changed = true, m_particles_sorted = false, m_box_changed = false, m_compute_adj = true;
@@ -1033,6 +1048,7 @@ class NeighborListGPUBinned : public Compute
     uint64_t m_cpos_tstep = ~0ull;
     uint64_t m_compute_tstep = 0;
     SpeculationHook m_speculate;
+    WordReadback m_readback;
     bool m_in_compute = false;
     uint64_t m_last_build_tstep = ~0ull;
 

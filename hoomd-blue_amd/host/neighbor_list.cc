@@ -392,9 +392,10 @@ void NeighborListGPUBinned::resizeNlist(size_t size)
 bool NeighborListGPUBinned::checkConditions()
     {
     const unsigned int nt = m_pdata->getNTypes();
-    unsigned int* h = m_h_words.get();
-    hipCheck(hipMemcpyAsync(h, m_conditions.get(), sizeof(unsigned int) * (nt + 2), hipMemcpyDeviceToHost, 0), "conditions D2H");
-    hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
+    if (nt + 2 > 64)
+        throw std::runtime_error("nlist: more than 62 particle types");
+    unsigned int h[64];
+    m_readback.read(m_conditions.get(), nt + 2, h, "neighbor list conditions");
     bool result = false;
     if (h[nt])
         {

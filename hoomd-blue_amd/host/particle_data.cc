@@ -41,6 +41,36 @@ unsigned int* PinnedWords::deviceView()
     return m_d;
     }
 
+void WordReadback::read(const unsigned int* d_words, unsigned int n, unsigned int* out, const char* what)
+    {
+    if (n == 0)
+        return;
+    if (n > 64)
+        throw std::runtime_error("WordReadback: more than 64 words");
+    m_stamp++;
+    abiCheck(hmd_publish_words(d_words, n, reinterpret_cast<unsigned long long*>(m_pinned.deviceView()), m_stamp, nullptr), "hmd_publish_words");
+    volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_pinned.get());
+    for (unsigned int k = 0; k < n; k++)
+        {
+        unsigned long long v = 0;
+        for (uint64_t spins = 0;; spins++)
+            {
+            v = h[k];
+            if ((unsigned int)(v >> 32) == m_stamp)
+                break;
+            __builtin_ia32_pause();
+            if ((spins & 0xfffff) == 0xfffff)
+                {
+                // surfaces a faulted kernel instead of spinning forever
+                hipError_t q = hipStreamQuery(0);
+                if (q != hipSuccess && q != hipErrorNotReady)
+                    hipCheck(q, what);
+                }
+            }
+        out[k] = (unsigned int)v;
+        }
+    }
+
 PinnedWords::~PinnedWords()
     {
     if (m_p)

@@ -179,6 +179,10 @@ int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* strea
    been reduced over the ranks of a domain decomposition (the role of the MPI_Allreduce in
    hoomd/md/NeighborListGPU.cc:86-98).  No counterpart kernel in the reference. */
 int hmd_publish_word(const unsigned int* d_word, unsigned long long* d_published, unsigned int stamp, void* stream);
+/* The same for n <= 64 consecutive words: d_published[k] = (stamp << 32 | d_words[k]).  Used for the overflow
+   conditions of the cell list and the neighbor list, which the reference reads back with a blocking copy
+   (hoomd/CellListGPU.cc:150-170, hoomd/md/NeighborListGPU.cc checkConditions). */
+int hmd_publish_words(const unsigned int* d_words, unsigned int n, unsigned long long* d_published, unsigned int stamp, void* stream);
 
 /* Replaces gpu_nlist_build_head_list (hoomd/md/NeighborListGPU.cu:415-456):
    d_head_list[i] = sum_{j<i} d_Nmax[type_j];  *d_req_size_nlist = sum over all N.
