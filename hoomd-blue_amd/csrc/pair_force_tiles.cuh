@@ -28,6 +28,12 @@ __device__ __forceinline__ pft_home_t pft_home(unsigned int idx, unsigned int nn
     return e;
     }
 
+// bytes of the home table: one entry per slot of the home cells and an empty one, padded to 16
+__host__ __device__ constexpr size_t pft_home_bytes(unsigned int cell_Nmax)
+    {
+    return (((size_t)TL_NH * cell_Nmax + 1) * sizeof(pft_home_t) + 15) / 16 * 16;
+    }
+
 typedef __attribute__((address_space(3))) const double pft_lds_double;
 
 // byte offset 8 * (16-bit half of w) in one instruction
@@ -76,7 +82,8 @@ __global__ void __launch_bounds__(PFT_THREADS)
     if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
         __builtin_trap(); // the toolchain placed something before the dynamic LDS
     const unsigned int np = a.ntypes * a.ntypes;
-    double* s_rcutsq = reinterpret_cast<double*>(s_home + TL_NH * g.cli.w + 1);
+    // (the 12-byte home entries end on any multiple of four: the tables of doubles behind them start 16-aligned)
+    double* s_rcutsq = reinterpret_cast<double*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES + pft_home_bytes(g.cli.w));
     double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
     unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
@@ -403,7 +410,7 @@ __global__ void __launch_bounds__(PFT_THREADS)
 
 template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned int ntypes, unsigned int cell_Nmax)
     {
-    size_t b = (size_t)tile_doubles(cap) * 8 + PFT_TABLES + ((size_t)TL_NH * cell_Nmax + 1) * sizeof(pft_home_t);
+    size_t b = (size_t)tile_doubles(cap) * 8 + PFT_TABLES + pft_home_bytes(cell_Nmax);
     if (ntypes > 1)
         b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + tile_doubles(cap);
     return (b + 15) / 16 * 16;
