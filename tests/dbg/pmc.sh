@@ -3,8 +3,8 @@
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/p1 -o p -- python3 $GRAFT_REPO_ROOT/scripts/dbg/tile_prof.py "$@" > $out.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT SQ_WAVES --output-format csv -d $out/p2 -o p -- python3 $GRAFT_REPO_ROOT/scripts/dbg/tile_prof.py "$@" >> $out.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/p1 -o p -- python3 $GRAFT_REPO_ROOT/tests/dbg/tile_prof.py "$@" > $out.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT SQ_WAVES --output-format csv -d $out/p2 -o p -- python3 $GRAFT_REPO_ROOT/tests/dbg/tile_prof.py "$@" >> $out.log 2>&1 || exit 1
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, glob, collections
