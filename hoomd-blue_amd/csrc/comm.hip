@@ -36,6 +36,67 @@ __global__ void __launch_bounds__(256) ghost_plan_kernel(hmd_ghost_plan_args_t a
     a.d_plan[idx] = plan & a.mask;
     }
 
+__device__ __forceinline__ unsigned int ghost_plan_of(const hmd_ghost_plan_args_t& a, unsigned int idx)
+    {
+    const double4 p = hmd_ld4(a.d_pos + idx);
+    const double rg = a.d_r_ghost[hmd_double_as_uint(p.w)];
+    const double gx = rg / a.box.nearest_plane[0], gy = rg / a.box.nearest_plane[1], gz = rg / a.box.nearest_plane[2];
+    hmd_scalar3 zero;
+    zero.x = zero.y = zero.z = 0.0;
+    const double3 f = hmd_make_fraction(a.box, p.x, p.y, p.z, zero);
+    unsigned int plan = 0;
+    if (f.x >= HMD_SUB(1.0, gx))
+        plan |= 1u;
+    if (f.x < gx)
+        plan |= 2u;
+    if (f.y >= HMD_SUB(1.0, gy))
+        plan |= 4u;
+    if (f.y < gy)
+        plan |= 8u;
+    if (f.z >= HMD_SUB(1.0, gz))
+        plan |= 16u;
+    if (f.z < gz)
+        plan |= 32u;
+    return plan & a.mask;
+    }
+
+__global__ void __launch_bounds__(256) ghost_send_list_kernel(hmd_ghost_send_list_args_t a)
+    {
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int plan = 0;
+    if (idx < a.ghost_plan.N)
+        {
+        plan = ghost_plan_of(a.ghost_plan, idx);
+        if (a.ghost_plan.d_plan)
+            a.ghost_plan.d_plan[idx] = plan;
+        }
+    if (!__ballot(plan != 0))
+        return; // no boundary particle in this wave
+    const unsigned int lane = threadIdx.x & 63;
+    for (unsigned int k = 0; k < a.n_dir; k++)
+        {
+        const unsigned int m = a.d_dir_mask[k];
+        const bool match = plan != 0 && (plan & m) == m;
+        const unsigned long long ballot = __ballot(match);
+        if (!ballot)
+            continue;
+        // one reservation per wave and direction
+        unsigned int base = 0;
+        if (lane == 0)
+            {
+            base = atomicAdd(a.d_total, (unsigned int)__popcll(ballot));
+            atomicAdd(a.d_dir_count + k, (unsigned int)__popcll(ballot));
+            }
+        base = __shfl(base, 0, 64);
+        if (match)
+            {
+            const unsigned int slot = base + hmd_rank_in_mask(ballot);
+            if (slot < a.capacity)
+                a.d_keys[slot] = ((unsigned long long)k << 32) | idx;
+            }
+        }
+    }
+
 __global__ void __launch_bounds__(256) migrate_dest_kernel(hmd_migrate_dest_args_t a)
     {
     const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,6 +173,20 @@ __global__ void __launch_bounds__(256) unpack_vote_kernel(hmd_unpack_vote_args_t
         hmd_st4(a.d_ghost_pos + m, p.x, p.y, p.z, p.w);
     else
         atomicMax(a.d_flag_word, hmd_double_as_uint(p.x));
+    }
+
+extern "C" int hmd_ghost_send_list(const hmd_ghost_send_list_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_send_list: args is NULL");
+    const hmd_ghost_plan_args_t& g = args->ghost_plan;
+    HMD_REQUIRE(g.d_pos && g.d_r_ghost && g.ntypes >= 1, HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_send_list: pos and r_ghost are required");
+    HMD_REQUIRE(args->d_total && args->d_dir_count, HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_send_list: total and dir_count are required");
+    HMD_REQUIRE(args->n_dir <= 26 && (args->n_dir == 0 || args->d_dir_mask), HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_send_list: at most 26 directions");
+    HMD_REQUIRE(args->capacity == 0 || args->d_keys, HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_send_list: d_keys is required");
+    if (g.N == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(ghost_send_list_kernel, dim3(hmd_div_up(g.N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
     }
 
 extern "C" int hmd_pack_ghost_positions_vote(const hmd_pack_vote_args_t* args, void* stream)

@@ -163,6 +163,11 @@ class MigrateDestArgs(C.Structure):
                 ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("rank", u32), ("d_dest", vp), ("d_n_leave", vp)]
 
 
+class GhostSendListArgs(C.Structure):
+    _fields_ = [("ghost_plan", GhostPlanArgs), ("d_dir_mask", vp), ("n_dir", u32), ("d_keys", vp), ("capacity", u32),
+                ("d_total", vp), ("d_dir_count", vp)]
+
+
 class PackPosArgs(C.Structure):
     _fields_ = [("d_out", vp), ("d_pos", vp), ("d_send_idx", vp), ("d_send_shift_id", vp), ("d_shift_table", vp),
                 ("n_send", u32)]
@@ -213,6 +218,7 @@ _SIGNATURES = {
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),
     "hmd_pack_ghost_positions_vote": (C.c_int, [C.POINTER(PackVoteArgs), vp]),
     "hmd_unpack_ghost_positions": (C.c_int, [C.POINTER(UnpackVoteArgs), vp]),
+    "hmd_ghost_send_list": (C.c_int, [C.POINTER(GhostSendListArgs), vp]),
     "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_publish_words": (C.c_int, [vp, u32, vp, u32, vp]),

@@ -323,6 +323,8 @@ class ParticleExchange:
         self._vote_out = None
         self._vote_in = None
         self.n_vote_exchanges = 0
+        self._keys = None
+        self._send_counters = None
 
     # ---- collectives ----
     def _a2a(self, out, inp, out_splits, in_splits):
@@ -426,18 +428,39 @@ class ParticleExchange:
         for a in range(3):
             if dd.decomposed[a] and width[a] <= 2.0 * r_ghost:
                 raise RuntimeError("Simulation box too small for domain decomposition: a sub-box must be wider than twice the ghost layer")
+        ndir = len(self.dir_dest)
         if self.device.type == "cuda":
-            plan = torch.empty(max(N, 1), dtype=torch.int32, device=self.device)[:N]
+            # plan, per-direction selection and counts in one kernel; one readback; one sort puts the keys
+            # (direction, particle index) in the order of the send list
+            m = _abi()
             ntypes = max(int(getattr(A, "ntypes", 1)), 1)
             if self._r_ghost is None or self._r_ghost.numel() != ntypes or float(self._r_ghost_value) != float(r_ghost):
                 self._r_ghost = torch.full((ntypes,), float(r_ghost), dtype=torch.float64, device=self.device)
                 self._r_ghost_value = float(r_ghost)
-            a = _abi().GhostPlanArgs()
-            a.d_plan, a.d_pos, a.N = plan.data_ptr(), A.pos.data_ptr(), N
-            a.box = _abi().Box.from_lo_hi(list(dd.lo), list(dd.hi))
-            a.d_r_ghost, a.ntypes = self._r_ghost.data_ptr(), ntypes
-            a.mask = sum(3 << (2 * ax) for ax in range(3) if dd.decomposed[ax])
-            _abi().check(_abi().lib.hmd_make_ghost_exchange_plan(ctypes.byref(a), None), "hmd_make_ghost_exchange_plan")
+            if self._keys is None:
+                self._keys = torch.empty(max(N // 2, 1024), dtype=torch.int64, device=self.device)
+                self._send_counters = torch.zeros(1 + 26, dtype=torch.int32, device=self.device)
+            a = m.GhostSendListArgs()
+            a.ghost_plan.d_plan, a.ghost_plan.d_pos, a.ghost_plan.N = None, A.pos.data_ptr(), N
+            a.ghost_plan.box = m.Box.from_lo_hi(list(dd.lo), list(dd.hi))
+            a.ghost_plan.d_r_ghost, a.ghost_plan.ntypes = self._r_ghost.data_ptr(), ntypes
+            a.ghost_plan.mask = sum(3 << (2 * ax) for ax in range(3) if dd.decomposed[ax])
+            a.d_dir_mask, a.n_dir = self.dir_mask.data_ptr(), ndir
+            while True:
+                self._send_counters.zero_()
+                a.d_keys, a.capacity = self._keys.data_ptr(), int(self._keys.numel())
+                a.d_total, a.d_dir_count = self._send_counters.data_ptr(), self._send_counters.data_ptr() + 4
+                m.check(m.lib.hmd_ghost_send_list(ctypes.byref(a), None), "hmd_ghost_send_list")
+                counters = self._send_counters.tolist()
+                if counters[0] <= self._keys.numel():
+                    break
+                self._keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
+            total, per_dir = counters[0], counters[1:1 + ndir]
+            keys, _ = torch.sort(self._keys[:total])
+            self.send_idx = (keys & 0xFFFFFFFF).contiguous()
+            dirs = keys >> 32
+            self.send_dir = dirs.to(torch.uint8).contiguous()
+            self.send_shift = self.shift_table[dirs].contiguous() if ndir else torch.zeros((0, 3), dtype=torch.float64, device=self.device)
         else:
             x = A.pos[:N, :3]
             f = (x - self.lo) / (self.hi - self.lo)
@@ -445,20 +468,19 @@ class ParticleExchange:
             bits = torch.tensor([[1, 4, 16], [2, 8, 32]], dtype=torch.int32, device=self.device)
             decm = self.dec.to(torch.int32)
             plan = (((f >= (1.0 - g)).to(torch.int32) * bits[0] + (f < g).to(torch.int32) * bits[1]) * decm).sum(dim=1, dtype=torch.int32)
-        b = torch.nonzero(plan).flatten()
-        ndir = len(self.dir_dest)
-        if ndir and b.numel():
-            m = (plan[b][None, :] & self.dir_mask[:, None]) == self.dir_mask[:, None]   # [ndir, nb]
-            nz = torch.nonzero(m)
-            per_dir = m.sum(dim=1).tolist()
-            self.send_idx = b[nz[:, 1]].contiguous()
-            self.send_dir = nz[:, 0].to(torch.uint8).contiguous()
-            self.send_shift = self.shift_table[nz[:, 0]].contiguous()
-        else:
-            per_dir = [0] * ndir
-            self.send_idx = torch.zeros(0, dtype=torch.int64, device=self.device)
-            self.send_dir = torch.zeros(0, dtype=torch.uint8, device=self.device)
-            self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=self.device)
+            b = torch.nonzero(plan).flatten()
+            if ndir and b.numel():
+                m = (plan[b][None, :] & self.dir_mask[:, None]) == self.dir_mask[:, None]   # [ndir, nb]
+                nz = torch.nonzero(m)
+                per_dir = m.sum(dim=1).tolist()
+                self.send_idx = b[nz[:, 1]].contiguous()
+                self.send_dir = nz[:, 0].to(torch.uint8).contiguous()
+                self.send_shift = self.shift_table[nz[:, 0]].contiguous()
+            else:
+                per_dir = [0] * ndir
+                self.send_idx = torch.zeros(0, dtype=torch.int64, device=self.device)
+                self.send_dir = torch.zeros(0, dtype=torch.uint8, device=self.device)
+                self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=self.device)
         self.send_idx32 = self.send_idx.to(torch.int32)
         send_counts = [0] * dd.world
         for k, n in enumerate(per_dir):

@@ -549,6 +549,26 @@ typedef struct
     } hmd_ghost_plan_args_t;
 int hmd_make_ghost_exchange_plan(const hmd_ghost_plan_args_t* args, void* stream);
 
+/* Plan and send list in one pass: for every owned particle and every entry k of d_dir_mask (a
+   combination of the plan bits above: one direction towards a neighboring domain, ghost_plan.mask limits
+   the bits as before) whose bits are all set in the particle's plan, the key (k << 32 | particle index) is
+   appended to d_keys and d_dir_count[k] is incremented; *d_total counts all keys, also those that did
+   not fit `capacity` (the caller grows the buffer and runs again).  Keys arrive in no particular order:
+   sorted, they are the send list ordered by direction, then particle index.  d_plan of ghost_plan may
+   be NULL.  The caller zeroes d_total and d_dir_count.  Covers gpu_make_ghost_exchange_plan plus the
+   per-direction selection and count of gpu_exchange_ghosts_make_indices (hoomd/CommunicatorGPU.cu:374-520). */
+typedef struct
+    {
+    hmd_ghost_plan_args_t ghost_plan;
+    const unsigned int* d_dir_mask;
+    unsigned int n_dir;            /* <= 26 */
+    unsigned long long* d_keys;
+    unsigned int capacity;
+    unsigned int* d_total;
+    unsigned int* d_dir_count;
+    } hmd_ghost_send_list_args_t;
+int hmd_ghost_send_list(const hmd_ghost_send_list_args_t* args, void* stream);
+
 /* out[k] = pos[d_send_idx[k]] + shift[d_send_shift_id[k]] (shift table of 27 periodic image
    vectors; id 13 = no shift).  Replaces gpu_pack_wrap_kernel / gpu_pack_kernel
    (hoomd/CommunicatorGPU.cu:778-875) for the position field. */

@@ -40,7 +40,7 @@ def test_ctypes_struct_layouts_match_the_header():
         "hmd_thermo_args_t": _abi.ThermoArgs, "hmd_cell_order_args_t": _abi.CellOrderArgs,
         "hmd_ghost_plan_args_t": _abi.GhostPlanArgs, "hmd_pack_pos_args_t": _abi.PackPosArgs,
         "hmd_migrate_dest_args_t": _abi.MigrateDestArgs, "hmd_pack_vote_args_t": _abi.PackVoteArgs,
-        "hmd_unpack_vote_args_t": _abi.UnpackVoteArgs, "hmd_bond_table_args_t": _abi.BondTableArgs, "hmd_bond_args_t": _abi.BondArgs,
+        "hmd_unpack_vote_args_t": _abi.UnpackVoteArgs, "hmd_ghost_send_list_args_t": _abi.GhostSendListArgs, "hmd_bond_table_args_t": _abi.BondTableArgs, "hmd_bond_args_t": _abi.BondArgs,
     }
     lines = ['#include "hoomd_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]
     for cname, ct in pairs.items():
