@@ -660,3 +660,38 @@ def test_migrate_dest_and_vote_rows(K, A):
     A.check(A.lib.hmd_publish_word(flag.data_ptr(), pinned.data_ptr(), 9, None), "hmd_publish_word")
     torch.cuda.synchronize()
     assert int(pinned.item()) == (9 << 32) | 57
+
+
+def test_ghost_send_list_keys(K, A):
+    import ctypes as C
+    rng = np.random.default_rng(33)
+    L = (10.0, 12.0, 14.0)
+    gbox, obox = boxes(A, L, periodic=(0, 0, 1))
+    N = 6000
+    xyz = (rng.random((N, 3)) - 0.5) * np.array(L)
+    typ = rng.integers(0, 2, N)
+    pos = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
+    rg = torch.tensor([2.5, 2.0], dtype=torch.float64, device="cuda")
+    # directions of a domain decomposed along x and y: 8 combinations of the x and y plan bits
+    masks = [1, 2, 4, 8, 1 | 4, 1 | 8, 2 | 4, 2 | 8]
+    dir_mask = torch.tensor(masks, dtype=torch.int32, device="cuda")
+    plan = torch.zeros(N, dtype=torch.int32, device="cuda")
+    counters = torch.zeros(1 + len(masks), dtype=torch.int32, device="cuda")
+    a = A.GhostSendListArgs()
+    a.ghost_plan.d_plan, a.ghost_plan.d_pos, a.ghost_plan.N, a.ghost_plan.box = plan.data_ptr(), pos.data_ptr(), N, gbox
+    a.ghost_plan.d_r_ghost, a.ghost_plan.ntypes, a.ghost_plan.mask = rg.data_ptr(), 2, 0b001111
+    a.d_dir_mask, a.n_dir = dir_mask.data_ptr(), len(masks)
+    a.d_total, a.d_dir_count = counters.data_ptr(), counters.data_ptr() + 4
+    want_plan = K.ghost_plan(pos, N, gbox, rg.cpu().numpy(), mask=0b001111).cpu().numpy()
+    want = sorted((k << 32) | i for k, m in enumerate(masks) for i in np.nonzero((want_plan & m) == m)[0].tolist())
+    # a buffer that is too small reports the need; the full one holds exactly the expected keys
+    for cap in (10, len(want) + 5):
+        keys = torch.full((cap,), -1, dtype=torch.int64, device="cuda")
+        counters.zero_()
+        a.d_keys, a.capacity = keys.data_ptr(), cap
+        A.check(A.lib.hmd_ghost_send_list(C.byref(a), None), "hmd_ghost_send_list")
+        c = counters.tolist()
+        assert c[0] == len(want)
+        assert c[1:] == [int(((want_plan & m) == m).sum()) for m in masks]
+    assert np.array_equal(plan.cpu().numpy(), want_plan)
+    assert sorted(keys[:len(want)].tolist()) == want and int(keys[len(want)]) == -1
