@@ -1,4 +1,4 @@
-"""Domain decomposition end to end on the GPU: 2 and 4 ranks (all on GPU 0, gloo transport) against
+"""Domain decomposition end to end on the GPU: 2, 4 and 8 ranks (all on GPU 0, gloo transport) against
 the single-domain run of the same system.  Trajectories agree to rounding (force sums run in a
 different neighbor order), energies and the rebuild cadence agree, particles migrate."""
 import os
@@ -13,22 +13,22 @@ sys.path.insert(0, HERE)
 from test_comm_gloo import launch  # noqa: E402
 
 
-@pytest.mark.parametrize("world,grid,sorter", [(2, (1, 1, 2), 0), (4, (2, 2, 1), 1)])
-def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter):
-    n, steps = (16, 16, 16), 60
+@pytest.mark.parametrize("world,grid,sorter,side", [(2, (1, 1, 2), 0, 16), (4, (2, 2, 1), 1, 16), (8, (2, 2, 2), 1, 20)])
+def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, side):
+    n, steps = (side, side, side), 60
     ref = str(tmp_path / "ref.npz")
     out = str(tmp_path / "dd.npz")
     launch("_dd_worker.py", 1, list((1, 1, 1)) + [ref] + list(n) + [steps, sorter], timeout=300)
     launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter], timeout=300)
     a, b = np.load(ref), np.load(out)
-    assert sum(b["N_local"]) == 16**3 and all(g > 0 for g in b["n_ghosts"])
+    assert sum(b["N_local"]) == side**3 and all(g > 0 for g in b["n_ghosts"])
     assert sum(b["migrated"]) > 0
     # every rank is every other rank's neighbor in these grids: the rebuild vote rode in the halo exchange
     assert min(b["vote_exchanges"]) > 0
     assert np.allclose(a["e0"], b["e0"], rtol=1e-11)
     assert np.allclose(a["e1"], b["e1"], rtol=1e-7)
     assert a["dof"] == b["dof"]
-    L = 16 * (1 / 0.84) ** (1 / 3)
+    L = side * (1 / 0.84) ** (1 / 3)
     ua = a["position"] + a["image"] * L
     ub = b["position"] + b["image"] * L
     assert np.abs(ua - ub).max() < 1e-7
