@@ -54,7 +54,8 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 // of four with the slot after the region's last candidate, where consumers keep a dummy far away.
 template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
 __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
-                                                                unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta)
+                                                                unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
+                                                                unsigned int* d_slot_of, hmd_scalar4* d_cpos)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
@@ -324,14 +325,27 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         if (TILE && d_slot_meta && lane < nh && hidx >= a.N && (lane % wpc) == sub)
             {
             hmd_uint4 m = {hidx, 0u, 0u, 0u}; // a ghost: no row
-            d_slot_meta[hmd_idx2(a.cli, hbase + lane, cell)] = m;
+            const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+            d_slot_meta[w] = m;
+            if (d_slot_of)
+                {
+                d_slot_of[hidx] = w;
+                hmd_st4(d_cpos + w, hx, hy, hz, a.d_pos[hidx].w);
+                }
             }
         if (lane < nh && hidx < a.N && (lane % wpc) == sub)
             {
             if (TILE && d_slot_meta)
                 {
                 hmd_uint4 m = {hidx, cnt, (unsigned int)(hhead / 4), 0u};
-                d_slot_meta[hmd_idx2(a.cli, hbase + lane, cell)] = m;
+                const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+                d_slot_meta[w] = m;
+                if (d_slot_of)
+                    {
+                    // the cell list holds the same bits as pos[hidx]: the slot-ordered copy starts out current
+                    d_slot_of[hidx] = w;
+                    hmd_st4(d_cpos + w, hx, hy, hz, a.d_pos[hidx].w);
+                    }
                 }
             a.d_n_neigh[hidx] = cnt;
             if (TILE)
@@ -522,7 +536,8 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
 
 template<bool ST, bool FB>
 int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
-                 unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr)
+                 unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr,
+                 unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr)
     {
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const dim3 grid(hmd_div_up(ncells, cells_per_block));
@@ -535,19 +550,19 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     if (d_tile)
         {
         HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
         }
     else if (fixed_images)
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
     else if (hmd_box_is_ortho(a.box))
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
     return hmd_launch_status();
     }
 
 int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow,
-                        hmd_uint4* d_slot_meta)
+                        hmd_uint4* d_slot_meta, unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr)
     {
     const bool single = (a.ntypes == 1);
     const bool fb = a.filter_body != 0;
@@ -560,12 +575,12 @@ int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigne
         wpc = 4;
     const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
     if (single && !fb)
-        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
     if (single && fb)
-        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
     if (!single && !fb)
-        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
-    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta);
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
     }
     } // namespace
 
@@ -635,7 +650,9 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     a.d_r_cut = t.d_r_cut;
     a.r_buff = t.r_buff;
     a.ntypes = t.ntypes;
-    return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta);
+    HMD_REQUIRE(!t.d_slot_of || (t.d_slot_meta && t.geom.d_cpos), HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_tiles: d_slot_of needs d_slot_meta and geom.d_cpos");
+    return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta, t.d_slot_of,
+                               t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr);
     }
 
 extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream)

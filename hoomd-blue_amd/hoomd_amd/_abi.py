@@ -192,7 +192,7 @@ class TileGeom(C.Structure):
 
 class NlistTilesArgs(C.Structure):
     _fields_ = [("geom", TileGeom), ("d_cell_xyzf", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp), ("cadji", Index2D),
-                ("d_tile_nlist", vp), ("d_slot_meta", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp),
+                ("d_tile_nlist", vp), ("d_slot_meta", vp), ("d_slot_of", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp),
                 ("d_Nmax", vp), ("d_head_list", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
                 ("ntypes", u32), ("d_tile_overflow", vp)]
 

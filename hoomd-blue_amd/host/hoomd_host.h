@@ -1045,7 +1045,7 @@ class NeighborListGPUBinned : public Compute
     //! time step whose distance check was already launched by the integrator's fused pass
     uint64_t m_prelaunched_tstep = ~0ull;
     //! time step for which the owned part of the slot-ordered position copy is already current
-    uint64_t m_cpos_tstep = ~0ull;
+    uint64_t m_cpos_tstep = ~0ull, m_cpos_all_tstep = ~0ull;
     uint64_t m_compute_tstep = 0;
     SpeculationHook m_speculate;
     WordReadback m_readback;

@@ -453,6 +453,7 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         m_tile_capacity = capacity;
         a.geom = getTileGeom();
         a.d_slot_meta = m_slot_meta.get();
+        a.d_slot_of = m_slot_of.get(); // the build also fills slot_of and the slot-ordered position copy
         a.d_cell_xyzf = m_cl->getXYZFArray().get();
         a.d_cell_type_body = m_cl->getTypeBodyArray().get();
         a.d_cell_adj = m_cl->getCellAdjArray().get();
@@ -472,7 +473,8 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         a.d_tile_overflow = m_conditions.get() + a.ntypes;
         hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
         abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
-        abiCheck(hmd_tile_slots(&a.geom, m_slot_of.get(), nullptr), "hmd_tile_slots");
+        m_cpos_tstep = timestep; // current for every particle, ghosts included
+        m_cpos_all_tstep = timestep;
         m_tiles_active = true;
         m_rows_valid = false;
         return;
@@ -523,6 +525,9 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
 void NeighborListGPUBinned::refreshTilePositions()
     {
     const unsigned int N = m_pdata->getN(), ng = m_pdata->getNGhosts();
+    // the build of this time step wrote every slot, ghosts included
+    if (m_cpos_all_tstep == m_compute_tstep)
+        return;
     // the integration pass may already have mirrored the owned particles of this time step
     const unsigned int first = (m_cpos_tstep == m_compute_tstep) ? N : 0u;
     if (first == N && ng == 0)

@@ -682,6 +682,8 @@ typedef struct
     hmd_index2d_t cadji;
     unsigned short* d_tile_nlist;
     hmd_uint4* d_slot_meta;          /* optional output, see hmd_tile_geom_t */
+    unsigned int* d_slot_of;         /* optional output with d_slot_meta and geom.d_cpos: d_slot_of[particle] = its slot
+                                        (what hmd_tile_slots computes) and d_cpos[slot] = its position (hmd_tile_refresh) */
     unsigned int* d_n_neigh;
     hmd_scalar4* d_last_updated_pos;
     unsigned int* d_conditions;      /* per type: largest row length seen (atomicMax), as the row-based build */
