@@ -58,15 +58,6 @@ __global__ void __launch_bounds__(PFT_THREADS)
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
     {
     typedef typename Ev::param_type param_t;
-    if (a.d_skip_flag)
-        {
-        const unsigned int word = *a.d_skip_flag;
-        if (a.d_published && blockIdx.x == 0 && threadIdx.x == 0)
-            __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        if (word == a.skip_value)
-            return;
-        }
     // All LDS of this kernel is dynamic and the tile comes first, so that the tile starts at LDS
     // address 0 and 8 * (row entry) is the address of a neighbor's x without adding a base.
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -78,9 +69,26 @@ __global__ void __launch_bounds__(PFT_THREADS)
     tile_tables& T = *reinterpret_cast<tile_tables*>(txyz + tile_len);
     // s_home: one entry per home particle and an empty one after the last
     unsigned int& s_next = *reinterpret_cast<unsigned int*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES - 16);
+    unsigned int& s_word = *reinterpret_cast<unsigned int*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES - 12);
     pft_home_t* s_home = reinterpret_cast<pft_home_t*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES);
     if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
         __builtin_trap(); // the toolchain placed something before the dynamic LDS
+    if (a.d_skip_flag)
+        {
+        // One thread reads the word for the whole workgroup: another stream may be raising it at this very
+        // moment (the rebuild vote of other ranks arriving), and a workgroup must not split over it.
+        if (threadIdx.x == 0)
+            {
+            const unsigned int word = __hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.d_published && blockIdx.x == 0)
+                __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            s_word = word;
+            }
+        __syncthreads();
+        if (s_word == a.skip_value)
+            return;
+        }
     const unsigned int np = a.ntypes * a.ntypes;
     // (the 12-byte home entries end on any multiple of four: the tables of doubles behind them start 16-aligned)
     double* s_rcutsq = reinterpret_cast<double*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES + pft_home_bytes(g.cli.w));
@@ -88,8 +96,59 @@ __global__ void __launch_bounds__(PFT_THREADS)
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
     unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
 
+    // which block of the grid: all of them in launch order, or those inside / outside a window
+    unsigned int vb = tile_xcd_remap(blockIdx.x, gridDim.x);
+    if (a.block_window_mode)
+        {
+        const unsigned int nbx = (g.ci.w + TB_X - 1) / TB_X, nby = (g.ci.h + TB_Y - 1) / TB_Y;
+        if (a.block_window_mode == 1)
+            {
+            // the launch covers the window only
+            const unsigned int wx = a.block_hi[0] - a.block_lo[0] + 1, wy = a.block_hi[1] - a.block_lo[1] + 1;
+            const unsigned int bx = a.block_lo[0] + vb % wx, by = a.block_lo[1] + (vb / wx) % wy, bz = a.block_lo[2] + vb / (wx * wy);
+            vb = (bz * nby + by) * nbx + bx;
+            }
+        else
+            {
+            // the launch covers the blocks outside the window: six slabs, numbered one after the other
+            const unsigned int nbz = (g.ci.d + TB_Z - 1) / TB_Z;
+            const unsigned int wy = a.block_hi[1] - a.block_lo[1] + 1, wz = a.block_hi[2] - a.block_lo[2] + 1;
+            unsigned int v = vb, bx, by, bz;
+            const unsigned int nA = nbx * nby * a.block_lo[2], nB = nbx * nby * (nbz - 1 - a.block_hi[2]);
+            const unsigned int nC = nbx * a.block_lo[1] * wz, nD = nbx * (nby - 1 - a.block_hi[1]) * wz;
+            const unsigned int nE = a.block_lo[0] * wy * wz;
+            if (v < nA)
+                {
+                bx = v % nbx, by = (v / nbx) % nby, bz = v / (nbx * nby);
+                }
+            else if ((v -= nA) < nB)
+                {
+                bx = v % nbx, by = (v / nbx) % nby, bz = a.block_hi[2] + 1 + v / (nbx * nby);
+                }
+            else if ((v -= nB) < nC)
+                {
+                bx = v % nbx, by = (v / nbx) % a.block_lo[1], bz = a.block_lo[2] + v / (nbx * a.block_lo[1]);
+                }
+            else if ((v -= nC) < nD)
+                {
+                const unsigned int hy = nby - 1 - a.block_hi[1];
+                bx = v % nbx, by = a.block_hi[1] + 1 + (v / nbx) % hy, bz = a.block_lo[2] + v / (nbx * hy);
+                }
+            else if ((v -= nD) < nE)
+                {
+                bx = v % a.block_lo[0], by = a.block_lo[1] + (v / a.block_lo[0]) % wy, bz = a.block_lo[2] + v / (a.block_lo[0] * wy);
+                }
+            else
+                {
+                v -= nE;
+                const unsigned int hx = nbx - 1 - a.block_hi[0];
+                bx = a.block_hi[0] + 1 + v % hx, by = a.block_lo[1] + (v / hx) % wy, bz = a.block_lo[2] + v / (hx * wy);
+                }
+            vb = (bz * nby + by) * nbx + bx;
+            }
+        }
     int cx0, cy0, cz0;
-    tile_setup(g, a.box, T, cx0, cy0, cz0);
+    tile_setup(g, a.box, T, cx0, cy0, cz0, vb);
     param_t p0;
     double rcutsq0 = 0.0, ronsq0 = 0.0;
     if (SINGLE_TYPE)
@@ -421,7 +480,15 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
                 const typename Ev::param_type* d_params, unsigned int tpp, hipStream_t s)
     {
     const size_t lds = pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w);
-    const dim3 grid(tile_num_blocks(g.ci)), block(PFT_THREADS);
+    unsigned int nblocks = tile_num_blocks(g.ci);
+    if (a.block_window_mode)
+        {
+        const unsigned int inside = (a.block_hi[0] - a.block_lo[0] + 1) * (a.block_hi[1] - a.block_lo[1] + 1) * (a.block_hi[2] - a.block_lo[2] + 1);
+        nblocks = a.block_window_mode == 1 ? inside : nblocks - inside;
+        if (nblocks == 0)
+            return HMD_OK; // the window is the whole grid: nothing outside it
+        }
+    const dim3 grid(nblocks), block(PFT_THREADS);
 #define HMD_PFT_LAUNCH(TPPV)                                                                                               \
     if (a.ntypes == 1)                                                                                                     \
         {                                                                                                                  \
@@ -470,6 +537,14 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
         return rc;
     HMD_REQUIRE(g.capacity >= 1 && g.capacity <= cap, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): geom.capacity must be in [1, 64 * cli.w]");
     HMD_REQUIRE(pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w) <= TL_MAX_LDS, HMD_ERR_TOO_LARGE, "pair forces (tiles): tile exceeds the LDS budget");
+    HMD_REQUIRE(a.block_window_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): block_window_mode must be 0, 1 or 2");
+    if (a.block_window_mode)
+        {
+        const unsigned int nb[3] = {(g.ci.w + TB_X - 1) / TB_X, (g.ci.h + TB_Y - 1) / TB_Y, (g.ci.d + TB_Z - 1) / TB_Z};
+        for (int d = 0; d < 3; d++)
+            HMD_REQUIRE(a.block_lo[d] <= a.block_hi[d] && a.block_hi[d] < nb[d], HMD_ERR_INVALID_ARGUMENT,
+                        "pair forces (tiles): the block window must lie inside the grid of blocks and hold at least one block");
+        }
     const unsigned int tpp = a.threads_per_particle ? a.threads_per_particle : 8;
     HMD_REQUIRE(tpp == 4 || tpp == 8 || tpp == 16, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): threads_per_particle must be 4, 8 or 16");
     if (a.N == 0)

@@ -139,10 +139,10 @@ __device__ __forceinline__ unsigned int tile_wave_scan(unsigned int v, int lane)
 
 // Fills the tables (threads 0..63 of the workgroup) and returns the block's cell coordinates of its
 // first home cell.  Callers __syncthreads() afterwards.
-__device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_box_t& box, tile_tables& T, int& cx0, int& cy0, int& cz0)
+// vb: number of the block in the grid of blocks (x fastest)
+__device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_box_t& box, tile_tables& T, int& cx0, int& cy0, int& cz0, unsigned int vb)
     {
     const unsigned int nbx = (g.ci.w + TB_X - 1) / TB_X, nby = (g.ci.h + TB_Y - 1) / TB_Y;
-    const unsigned int vb = tile_xcd_remap(blockIdx.x, gridDim.x);
     cx0 = TB_X * (int)(vb % nbx);
     cy0 = TB_Y * (int)((vb / nbx) % nby);
     cz0 = TB_Z * (int)(vb / (nbx * nby));
@@ -167,6 +167,11 @@ __device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_b
             T.img[d][r] = !box.periodic[d] ? 0.0 : c < 0 ? -1.0 : c >= dim ? 1.0 : 0.0;
             }
         }
+    }
+
+__device__ __forceinline__ void tile_setup(const hmd_tile_geom_t& g, const hmd_box_t& box, tile_tables& T, int& cx0, int& cy0, int& cz0)
+    {
+    tile_setup(g, box, T, cx0, cy0, cz0, tile_xcd_remap(blockIdx.x, gridDim.x));
     }
 
 // Coordinates of a member of region cell rc as the home cells see it: the periodic image nearest to

@@ -120,7 +120,8 @@ class PairArgs(C.Structure):
                 ("d_pos", vp), ("d_charge", vp), ("box", Box), ("d_n_neigh", vp), ("d_nlist", vp), ("d_head_list", vp),
                 ("d_rcutsq", vp), ("d_ronsq", vp), ("size_neigh_list", C.c_size_t), ("ntypes", u32),
                 ("block_size", u32), ("shift_mode", u32), ("compute_virial", u32), ("threads_per_particle", u32),
-                ("d_skip_flag", vp), ("skip_value", u32), ("publish_stamp", u32), ("d_published", vp)]
+                ("d_skip_flag", vp), ("skip_value", u32), ("publish_stamp", u32), ("d_published", vp),
+                ("block_window_mode", u32), ("block_lo", u32 * 3), ("block_hi", u32 * 3)]
 
 
 class ForceList(C.Structure):

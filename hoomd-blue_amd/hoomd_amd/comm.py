@@ -325,6 +325,7 @@ class ParticleExchange:
         self.n_vote_exchanges = 0
         self._keys = None
         self._send_counters = None
+        self._stream = None  # HIP stream handle for the per-step exchange kernels (None = the default stream)
 
     # ---- collectives ----
     def _a2a(self, out, inp, out_splits, in_splits):
@@ -552,12 +553,12 @@ class ParticleExchange:
         a.pack.d_shift_table, a.pack.n_send = self.shift_table.data_ptr(), int(self.send_idx32.numel())
         a.d_out_row, a.d_flag_word = vp["out_row"].data_ptr(), d_flag
         a.d_flag_rows, a.n_flag_rows = vp["flag_rows"].data_ptr(), int(vp["flag_rows"].numel())
-        m.check(m.lib.hmd_pack_ghost_positions_vote(ctypes.byref(a), None), "hmd_pack_ghost_positions_vote")
+        m.check(m.lib.hmd_pack_ghost_positions_vote(ctypes.byref(a), self._stream), "hmd_pack_ghost_positions_vote")
         self._a2a(self._vote_in[:vp["n_in"]], self._vote_out[:vp["n_out"]], vp["aug_recv"], vp["aug_send"])
         u = m.UnpackVoteArgs()
         u.d_in, u.d_map, u.n_rows = self._vote_in.data_ptr(), vp["in_map"].data_ptr(), vp["n_in"]
         u.d_ghost_pos, u.d_flag_word = A.pos.data_ptr() + 32 * A.N, d_flag
-        m.check(m.lib.hmd_unpack_ghost_positions(ctypes.byref(u), None), "hmd_unpack_ghost_positions")
+        m.check(m.lib.hmd_unpack_ghost_positions(ctypes.byref(u), self._stream), "hmd_unpack_ghost_positions")
 
     def pack(self):
         A = self.arrays
@@ -597,6 +598,7 @@ class Communicator(_cpp.Communicator):
         self._vote = None
         self._in_communicate = False
         self._ghosts_fresh = False
+        self._side = None
         self.use_vote_rows = os.environ.get("HOOMD_AMD_VOTE_ROWS", "1") != "0"
         self.exchange = ParticleExchange(decomposition, PDataArrays(self.pdata), pack_fn=self._pack_kernel)
 
@@ -614,7 +616,7 @@ class Communicator(_cpp.Communicator):
             a.d_send_shift_id = ex.send_dir.data_ptr()
             a.d_shift_table = ex.shift_table.data_ptr()
             a.n_send = n
-            _abi.check(_abi.lib.hmd_pack_ghost_positions(ctypes.byref(a), None), "hmd_pack_ghost_positions")
+            _abi.check(_abi.lib.hmd_pack_ghost_positions(ctypes.byref(a), ex._stream), "hmd_pack_ghost_positions")
         return out
 
     # -- interface called from C++ --
@@ -631,12 +633,26 @@ class Communicator(_cpp.Communicator):
     def anyRank(self, local):
         return self.exchange.any_rank(bool(local))
 
-    def beginRebuildVote(self, d_flag, checkn):
+    def beginRebuildVote(self, d_flag, checkn, stream=0):
         """Device-side rebuild vote: the flag word of the distance check (the number of the last check that
         found the list stale, the same count on every rank) is MAX-reduced in place over all ranks, with no
         host round trip between the distance check and the reduction.
         On the (common) steps where only ghost positions need refreshing the halo exchange is queued first,
-        so one wait covers both and work predicated on the vote can be queued behind it."""
+        so one wait covers both and work predicated on the vote can be queued behind it.
+        stream: HIP stream to queue all of this on (0: the default stream)."""
+        if not stream:
+            return self._begin_rebuild_vote(d_flag, checkn)
+        if self._side is None or self._side[0] != stream:
+            self._side = (stream, torch.cuda.ExternalStream(stream))
+        ex = self.exchange
+        ex._stream = stream
+        try:
+            with torch.cuda.stream(self._side[1]):
+                return self._begin_rebuild_vote(d_flag, checkn)
+        finally:
+            ex._stream = None
+
+    def _begin_rebuild_vote(self, d_flag, checkn):
         ex = self.exchange
         if self._flag_view is None or self._flag_view[0] != d_flag:
             self._flag_view = (d_flag, torch.as_tensor(_DevMem(d_flag, (1,), "<i4"), device=ex.device))

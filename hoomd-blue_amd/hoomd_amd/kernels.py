@@ -253,18 +253,28 @@ def tile_refresh(pos, tl):
     return cpos
 
 
-def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, shift_mode=0, compute_virial=True, tpp=0, n_total=None, fast=False):
+def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, shift_mode=0, compute_virial=True, tpp=0, n_total=None, fast=False,
+                      window=None, into=None):
+    """window: (mode, lo[3], hi[3]) restricts the launch to the blocks inside (1) or outside (2) a window of the
+    grid of 2x2x2-cell blocks; into: (force, virial) arrays of an earlier call to write into."""
     dev = pos.device
     n_total = pos.shape[0] if n_total is None else n_total
     prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
     rc = torch.as_tensor(np.asarray(rcutsq, dtype=np.float64), device=dev).contiguous()
     nt = rc.shape[0]
     ro = torch.as_tensor(np.asarray(ronsq if ronsq is not None else np.zeros((nt, nt)), dtype=np.float64), device=dev).contiguous()
-    force = torch.full((n_total, 4), float("nan"), dtype=torch.float64, device=dev)
-    virial = torch.full((6, n_total), float("nan"), dtype=torch.float64, device=dev) if compute_virial else None
+    if into is not None:
+        force, virial = into
+    else:
+        force = torch.full((n_total, 4), float("nan"), dtype=torch.float64, device=dev)
+        virial = torch.full((6, n_total), float("nan"), dtype=torch.float64, device=dev) if compute_virial else None
     a = _abi.PairArgs()
     a.d_force, a.d_virial, a.virial_pitch = ptr(force), ptr(virial), n_total
     a.N, a.n_max, a.d_pos, a.box = N, n_total, ptr(pos), box
+    if window is not None:
+        a.block_window_mode = window[0]
+        for d in range(3):
+            a.block_lo[d], a.block_hi[d] = window[1][d], window[2][d]
     a.d_n_neigh, a.d_nlist, a.d_head_list = ptr(tl["n_neigh"]), None, ptr(tl["head"])
     a.d_rcutsq, a.d_ronsq, a.size_neigh_list, a.ntypes = ptr(rc), ptr(ro), tl["tiles"].numel(), nt
     a.shift_mode, a.compute_virial, a.threads_per_particle = shift_mode, int(compute_virial), tpp

@@ -122,8 +122,11 @@ PotentialPairGPU<Ev>::PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef,
                                        unsigned int stamp)
                                 {
                                 m_spec_tstep = timestep;
-                                return launchKernel(d_flag, stale, d_published, stamp);
+                                // the interior blocks of this step may already be running on the side stream
+                                return launchKernel(d_flag, stale, d_published, stamp, m_interior_tstep == timestep ? 2u : 0u);
                                 });
+    m_nlist->setInteriorHook([this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale)
+                             { return launchInterior(timestep, d_flag, stale); });
     m_d_params.resize(np);
     m_d_rcutsq.resize(np);
     m_d_ronsq.resize(np);
@@ -134,8 +137,23 @@ template<class Ev> PotentialPairGPU<Ev>::~PotentialPairGPU()
     if (m_nlist)
         {
         m_nlist->setSpeculationHook(nullptr);
+        m_nlist->setInteriorHook(nullptr);
         m_nlist->removeRCutMatrix(m_r_cut_nlist);
         }
+    }
+
+// Queue the tile blocks that see no ghosts, predicated on the local result of the distance check, before the
+// halo exchange is queued (on another stream): they run while the ghost positions travel.  When another rank
+// votes for a rebuild their result is simply overwritten by the launch that follows the rebuild.
+template<class Ev> bool PotentialPairGPU<Ev>::launchInterior(uint64_t timestep, const unsigned int* d_flag, unsigned int stale)
+    {
+    if (!m_nlist->tilesActive() || m_pdata->getN() == 0)
+        return false;
+    if (!m_nlist->getInteriorBlockWindow(timestep, m_win_lo, m_win_hi))
+        return false;
+    launchKernel(d_flag, stale, nullptr, 0, 1u);
+    m_interior_tstep = timestep;
+    return true;
     }
 
 // hoomd/md/PotentialPair.h:467-482 (symmetric assignment)
@@ -190,7 +208,8 @@ template<class Ev> void PotentialPairGPU<Ev>::computeForces(uint64_t timestep)
     }
 
 template<class Ev>
-bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published, unsigned int stamp)
+bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published, unsigned int stamp,
+                                        unsigned int part)
     {
     if (m_tables_dirty)
         {
@@ -235,9 +254,18 @@ bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigne
     a.skip_value = skip_value;
     a.d_published = d_published;
     a.publish_stamp = stamp;
-    if (tiles)
+    if (part)
+        {
+        a.block_window_mode = part;
+        for (int d = 0; d < 3; d++)
+            {
+            a.block_lo[d] = m_win_lo[d];
+            a.block_hi[d] = m_win_hi[d];
+            }
+        }
+    if (tiles && part != 1) // (the interior blocks read owned particles only, whose copies are current)
         m_nlist->refreshTilePositions();
-    ScopedKernelTimer t("pair_force");
+    ScopedKernelTimer t(part == 1 ? "pair_force_interior" : "pair_force");
     if (tiles)
         {
         const hmd_tile_geom_t g = m_nlist->getTileGeom();

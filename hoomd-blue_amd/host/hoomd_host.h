@@ -591,7 +591,8 @@ class Communicator
     //! afterwards it equals checkn on every rank iff the list of any rank is stale (0 = not supported: fall
     //! back to anyRank).  The caller reads the word itself (hmd_publish_word); endRebuildVote() is the slow
     //! way to the same answer.
-    virtual uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn)
+    //! stream: HIP stream to queue the exchange on (0 = the default stream)
+    virtual uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn, uintptr_t stream)
         {
         return 0;
         }
@@ -976,6 +977,32 @@ class NeighborListGPUBinned : public Compute
         {
         m_speculate = h;
         }
+    //! Under domain decomposition, called after the distance check has been queued and before the halo
+    //! exchange is: (time step, device word of the check, value that means "stale").  The consumer may queue
+    //! work that needs no ghost positions on the default stream; the exchange is then queued on a stream of
+    //! its own and runs beside that work.
+    typedef std::function<bool(uint64_t, const unsigned int*, unsigned int)> InteriorHook;
+    void setInteriorHook(InteriorHook h)
+        {
+        m_interior_hook = h;
+        }
+    //! Window of tile blocks (2x2x2 cells) whose 4x4x4-cell regions hold no ghost particles; false when
+    //! there is none, the tile path is off, or the slot-ordered positions of the owned particles are not
+    //! those of `timestep`.
+    bool getInteriorBlockWindow(uint64_t timestep, unsigned int (&lo)[3], unsigned int (&hi)[3]) const;
+    void setOverlapEnabled(bool b)
+        {
+        m_overlap = b;
+        }
+    bool getOverlapEnabled() const
+        {
+        return m_overlap;
+        }
+    //! number of time steps whose interior blocks ran during the halo exchange
+    uint64_t getNumOverlapped() const
+        {
+        return m_n_overlapped;
+        }
     //! time step of the last (re)build
     uint64_t getLastBuildTimestep() const
         {
@@ -1048,6 +1075,11 @@ class NeighborListGPUBinned : public Compute
     uint64_t m_cpos_tstep = ~0ull, m_cpos_all_tstep = ~0ull;
     uint64_t m_compute_tstep = 0;
     SpeculationHook m_speculate;
+    InteriorHook m_interior_hook;
+    hipStream_t m_comm_stream = nullptr;
+    hipEvent_t m_ev_ready = nullptr, m_ev_comm = nullptr;
+    bool m_overlap = true;
+    uint64_t m_n_overlapped = 0;
     WordReadback m_readback;
     bool m_in_compute = false;
     uint64_t m_last_build_tstep = ~0ull;
@@ -1232,9 +1264,16 @@ template<class Ev> class PotentialPairGPU : public ForceCompute
 
     protected:
     void computeForces(uint64_t timestep) override;
-    bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0);
+    //! part: 0 every particle; 1 the blocks of tiles that see no ghosts; 2 the other blocks
+    bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0,
+                      unsigned int part = 0);
+    bool launchInterior(uint64_t timestep, const unsigned int* d_flag, unsigned int stale);
     void computeTailCorrection();
     uint64_t m_spec_tstep = ~0ull; // time step whose force kernel was queued speculatively
+    // Under domain decomposition the tile blocks that see no ghosts are queued before the halo exchange
+    // (which runs on a stream of its own), the other blocks behind it.
+    uint64_t m_interior_tstep = ~0ull; // time step whose interior blocks were queued ahead of the exchange
+    unsigned int m_win_lo[3] = {0, 0, 0}, m_win_hi[3] = {0, 0, 0};
     std::shared_ptr<NeighborListGPUBinned> m_nlist;
     unsigned int m_ntypes;
     energyShiftMode m_shift_mode = no_shift;
@@ -1600,7 +1639,7 @@ struct KernelTimer
     {
     static KernelTimer& get();
     void enable(bool on);
-    //! time only the kernel with this name ("" = all)
+    //! time only the kernels whose names start with this ("" = all)
     void setFilter(const std::string& name)
         {
         m_filter = name;
@@ -1616,9 +1655,9 @@ struct KernelTimer
         }
     bool wants(const char* name) const
         {
-        return m_on && (m_filter.empty() || m_filter == name);
+        return m_on && (m_filter.empty() || std::strncmp(name, m_filter.c_str(), m_filter.size()) == 0);
         }
-    void begin(const char* name);
+    void begin(const char* name, hipStream_t stream = nullptr);
     void end(const char* name);
     //! name -> (count, total ms); synchronizes the stream
     std::vector<std::tuple<std::string, uint64_t, double>> collect();
@@ -1632,6 +1671,7 @@ struct KernelTimer
         {
         std::string name;
         hipEvent_t e0, e1;
+        hipStream_t stream;
         };
     std::vector<Rec> m_open, m_done;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pool;
@@ -1642,10 +1682,10 @@ struct ScopedKernelTimer
     {
     const char* n;
     bool on;
-    explicit ScopedKernelTimer(const char* name) : n(name), on(KernelTimer::get().wants(name))
+    explicit ScopedKernelTimer(const char* name, hipStream_t stream = nullptr) : n(name), on(KernelTimer::get().wants(name))
         {
         if (on)
-            KernelTimer::get().begin(n);
+            KernelTimer::get().begin(n, stream);
         }
     ~ScopedKernelTimer()
         {

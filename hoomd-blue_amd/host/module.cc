@@ -117,9 +117,9 @@ class PyCommunicator : public Communicator
         {
         PYBIND11_OVERRIDE_PURE(bool, Communicator, anyRank, local);
         }
-    uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn) override
+    uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn, uintptr_t stream) override
         {
-        PYBIND11_OVERRIDE(uintptr_t, Communicator, beginRebuildVote, d_flag, checkn);
+        PYBIND11_OVERRIDE(uintptr_t, Communicator, beginRebuildVote, d_flag, checkn, stream);
         }
     bool endRebuildVote() override
         {
@@ -335,6 +335,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("tiles", &NeighborListGPUBinned::getTilesEnabled, &NeighborListGPUBinned::setTilesEnabled)
         .def_property_readonly("tiles_active", &NeighborListGPUBinned::tilesActive)
         .def_property_readonly("tile_capacity", &NeighborListGPUBinned::getTileCapacity)
+        .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)
+        .def_property_readonly("num_overlapped", &NeighborListGPUBinned::getNumOverlapped)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)
         .def("setFilterBody", &NeighborListGPUBinned::setFilterBody)

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace hoomd_amd
     {
@@ -54,6 +55,13 @@ NeighborListGPUBinned::~NeighborListGPUBinned()
     m_pdata->getParticleSortSignal().disconnect(m_sort_slot);
     m_pdata->getBoxChangeSignal().disconnect(m_box_slot);
     m_pdata->getMaxParticleNumberChangeSignal().disconnect(m_maxn_slot);
+    if (m_comm_stream)
+        {
+        hipStreamSynchronize(m_comm_stream);
+        hipStreamDestroy(m_comm_stream);
+        hipEventDestroy(m_ev_ready);
+        hipEventDestroy(m_ev_comm);
+        }
     }
 
 void NeighborListGPUBinned::reallocatePerParticle()
@@ -229,14 +237,54 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         // refreshes the ghost positions in the same breath, so work that is valid for a fresh list can be
         // queued behind the vote before the host has seen it
         auto comm = m_sysdef->getCommunicator();
-        const uintptr_t d_vote = comm->beginRebuildVote((uintptr_t)m_flag.get(), m_checkn);
+        // Work that needs no ghost positions is queued first, on the default stream; the exchange then goes on
+        // a stream of its own that waits only for what was queued before that work (integration, distance
+        // check), so the two run side by side.  The default stream waits for the exchange before it goes on.
+        bool overlapped = false;
+        if (m_overlap && m_interior_hook)
+            {
+            if (!m_comm_stream)
+                {
+                // highest priority: the runtime keeps such streams on hardware queues of their own, so the
+                // exchange's small kernels are not lined up behind the force kernel of the default stream
+                // (HOOMD_AMD_COMM_PRIORITY=normal: for several processes sharing one GPU, whose high-priority
+                // queues waiting on their normal-priority ones can starve each other)
+                int least = 0, greatest = 0;
+                hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+                const char* prio = std::getenv("HOOMD_AMD_COMM_PRIORITY");
+                const bool high = !(prio && std::string(prio) == "normal");
+                hipCheck(hipStreamCreateWithPriority(&m_comm_stream, hipStreamNonBlocking, high ? greatest : 0), "hipStreamCreateWithPriority");
+                hipCheck(hipEventCreateWithFlags(&m_ev_ready, hipEventDisableTiming), "hipEventCreateWithFlags");
+                hipCheck(hipEventCreateWithFlags(&m_ev_comm, hipEventDisableTiming), "hipEventCreateWithFlags");
+                }
+            hipCheck(hipEventRecord(m_ev_ready, nullptr), "hipEventRecord");
+            overlapped = m_interior_hook(timestep, m_flag.get(), m_checkn);
+            if (overlapped)
+                {
+                hipCheck(hipStreamWaitEvent(m_comm_stream, m_ev_ready, 0), "hipStreamWaitEvent");
+                m_n_overlapped++;
+                }
+            }
+        const uintptr_t d_vote = comm->beginRebuildVote((uintptr_t)m_flag.get(), m_checkn, overlapped ? (uintptr_t)m_comm_stream : 0);
+        if (overlapped && !d_vote)
+            hipCheck(hipStreamSynchronize(m_comm_stream), "hipStreamSynchronize");
         if (d_vote)
             {
             const unsigned int* d_word = reinterpret_cast<const unsigned int*>(d_vote);
             // the reduced word reaches the host like the local one does: published to pinned memory, polled
             volatile unsigned long long* hv = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 20);
             unsigned long long* d_pub = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 20);
-            if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn)))
+            if (overlapped)
+                {
+                // the exchange's stream hands the vote to the host as soon as it is known, long before the
+                // default stream gets to the remaining blocks
+                abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, m_comm_stream), "hmd_publish_word");
+                hipCheck(hipEventRecord(m_ev_comm, m_comm_stream), "hipEventRecord");
+                hipCheck(hipStreamWaitEvent(nullptr, m_ev_comm, 0), "hipStreamWaitEvent");
+                if (m_speculate)
+                    m_speculate(timestep, d_word, m_checkn, nullptr, 0);
+                }
+            else if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn)))
                 abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, nullptr), "hmd_publish_word");
             unsigned long long v = 0;
             for (uint64_t spins = 0;; spins++)
@@ -520,6 +568,44 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
     g.d_cpos = m_cpos.get();
     g.d_slot_meta = m_slot_meta.get();
     return g;
+    }
+
+// A ghost lies outside the local box along at least one decomposed axis when the cell list is filled (it is
+// owned by another rank), so along such an axis it sits in a cell that reaches beyond the box: cell c covers
+// [c, c+1) * (L + 2 ghost_width) / dim of the padded box (hoomd/CellList.cc:447-476).  A block of 2x2x2 cells
+// sees the cells 2b-1 .. 2b+2 along each axis; it is interior when all of those lie wholly inside the box
+// along every decomposed axis.
+bool NeighborListGPUBinned::getInteriorBlockWindow(uint64_t timestep, unsigned int (&lo)[3], unsigned int (&hi)[3]) const
+    {
+    if (!m_tiles_active || m_cpos_tstep != timestep || m_compute_tstep != timestep)
+        return false;
+    const hmd_index3d_t ci = m_cl->getCellIndexer();
+    const unsigned int dim[3] = {ci.w, ci.h, ci.d};
+    const Scalar3 gw3 = m_cl->getGhostWidth();
+    const Scalar gw[3] = {gw3.x, gw3.y, gw3.z};
+    const hmd_box_t box = m_pdata->getBox().b;
+    for (int d = 0; d < 3; d++)
+        {
+        const unsigned int nb = (dim[d] + 1) / 2;
+        if (gw[d] <= 0)
+            {
+            lo[d] = 0;
+            hi[d] = nb - 1;
+            continue;
+            }
+        const double W = (box.L[d] + 2.0 * gw[d]) / dim[d];
+        // first and last cell wholly inside the box, with a margin far above the rounding of the binning
+        const long first = (long)std::floor(gw[d] / W + 1e-3) + 1;
+        const long last = (long)std::floor((gw[d] + box.L[d]) / W - 1e-3) - 1;
+        // region of block b: cells max(2b-1, 0) .. min(2b+2, dim-1)
+        const long blo = (first + 2) / 2;                   // smallest b with 2b-1 >= first
+        const long bhi = last >= 2 ? (last - 2) / 2 : -1; // largest b with 2b+2 <= last
+        if (first < 1 || bhi < blo || bhi >= (long)nb)
+            return false;
+        lo[d] = (unsigned int)blo;
+        hi[d] = (unsigned int)bhi;
+        }
+    return true;
     }
 
 void NeighborListGPUBinned::refreshTilePositions()

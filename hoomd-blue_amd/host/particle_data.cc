@@ -363,10 +363,11 @@ void KernelTimer::enable(bool on)
     m_on = on;
     }
 
-void KernelTimer::begin(const char* name)
+void KernelTimer::begin(const char* name, hipStream_t stream)
     {
     Rec r;
     r.name = name;
+    r.stream = stream;
     if (!m_pool.empty())
         {
         r.e0 = m_pool.back().first;
@@ -378,7 +379,7 @@ void KernelTimer::begin(const char* name)
         hipCheck(hipEventCreate(&r.e0), "hipEventCreate");
         hipCheck(hipEventCreate(&r.e1), "hipEventCreate");
         }
-    hipCheck(hipEventRecord(r.e0, 0), "hipEventRecord");
+    hipCheck(hipEventRecord(r.e0, stream), "hipEventRecord");
     m_open.push_back(r);
     }
 
@@ -387,7 +388,7 @@ void KernelTimer::end(const char* name)
     for (size_t i = m_open.size(); i-- > 0;)
         if (m_open[i].name == name)
             {
-            hipCheck(hipEventRecord(m_open[i].e1, 0), "hipEventRecord");
+            hipCheck(hipEventRecord(m_open[i].e1, m_open[i].stream), "hipEventRecord");
             m_done.push_back(m_open[i]);
             m_open.erase(m_open.begin() + i);
             break;
@@ -403,6 +404,8 @@ std::vector<std::tuple<std::string, uint64_t, double>> KernelTimer::collect()
     for (auto& r : m_done)
         {
         float ms = 0;
+        if (r.stream)
+            hipCheck(hipEventSynchronize(r.e1), "hipEventSynchronize");
         hipCheck(hipEventElapsedTime(&ms, r.e0, r.e1), "hipEventElapsedTime");
         if (ms < m_min_ms)
             r.name += "_skipped";

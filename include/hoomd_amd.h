@@ -311,6 +311,15 @@ typedef struct
        (publish_stamp << 32 | *d_skip_flag) to d_published as hmd_publish_word would, before anything else. */
     unsigned int publish_stamp;
     unsigned long long* d_published;
+    /* Tile entry points only (ignored by the row-based ones): which blocks of 2x2x2 cells this launch
+       serves.  0: all; 1: the blocks b with block_lo[d] <= b[d] <= block_hi[d] on every axis d;
+       2: all blocks outside that window.  Under domain decomposition a caller computes the window of
+       blocks whose 4x4x4 regions hold no ghosts while the ghost positions are still in flight (mode 1,
+       on its own stream) and the rest once they have arrived (mode 2).  The reference has no such
+       split: it waits for the ghosts, then launches over all particles (hoomd/md/PotentialPairGPU.h:89-160). */
+    unsigned int block_window_mode;
+    unsigned int block_lo[3];
+    unsigned int block_hi[3];
     } hmd_pair_args_t;
 
 /* EvaluatorPairLJ::param_type (hoomd/md/EvaluatorPairLJ.h:99-155) */

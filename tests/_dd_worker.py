@@ -51,6 +51,11 @@ def main():
     n = tuple(int(v) for v in sys.argv[8:11])
     steps = int(sys.argv[11])
     sorter = bool(int(sys.argv[12]))
+    if world > 1:
+        # Several processes share one GPU here.  Their high-priority queues, each waiting for an event of the
+        # same process's normal-priority queue, were seen to starve each other (runs hung now and then);
+        # with one process per GPU, as in production, there is no such competition.
+        os.environ["HOOMD_AMD_COMM_PRIORITY"] = "normal"
     import hoomd_amd as hoomd
     dd = None
     if world > 1:
@@ -66,7 +71,8 @@ def main():
     e1 = (thermo.kinetic_energy, thermo.potential_energy)
     s = sim.state.get_snapshot()
     dof = thermo.degrees_of_freedom  # collective under domain decomposition: every rank asks
-    stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds))
+    stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds),
+                 overlapped=int(cell._cpp_obj.num_overlapped))
     if dd is not None:
         ex = dd.communicator.exchange
         stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges))
@@ -78,7 +84,7 @@ def main():
         np.savez(out, position=s.particles.position, velocity=s.particles.velocity, image=s.particles.image, e0=e0, e1=e1,
                  dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
                  builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats],
-                 vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats])
+                 vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats], overlapped=[a["overlapped"] for a in allstats])
     if dd is not None:
         dist.barrier()
         dist.destroy_process_group()

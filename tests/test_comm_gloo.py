@@ -20,20 +20,48 @@ def free_port():
 
 
 def launch(script, world, extra, timeout=240, env=None):
+    """One process per rank.  A rank that fails ends the run at once (the others would wait for it in a
+    collective until the time limit) and its output is what the assertion shows."""
+    import tempfile
+    import time
     port = free_port()
+    logs = [tempfile.TemporaryFile() for _ in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, script), str(r), str(world), str(port)] + [str(e) for e in extra],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
-    outs = []
+                              stdout=logs[r], stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    deadline = time.monotonic() + timeout
+    failed = None
     try:
-        for p in procs:
-            out, _ = p.communicate(timeout=timeout)
-            outs.append(out.decode(errors="replace"))
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                failed = next(r for r, c in enumerate(codes) if c is None)
+                # workers that registered faulthandler on SIGUSR1 print where they are stuck
+                import signal
+                for p in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGUSR1)
+                time.sleep(2.0)
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} failed:\n{o[-4000:]}"
+                p.wait()
+    outs = []
+    for f in logs:
+        f.seek(0)
+        outs.append(f.read().decode(errors="replace"))
+        f.close()
+    if failed is not None:
+        others = "".join(f"\n---- rank {r} ----\n{o[-1500:]}" for r, o in enumerate(outs) if r != failed)
+        raise AssertionError(f"rank {failed} failed or timed out (exit code {procs[failed].returncode}):\n{outs[failed][-4000:]}{others}")
     return outs
 
 

@@ -13,22 +13,30 @@ sys.path.insert(0, HERE)
 from test_comm_gloo import launch  # noqa: E402
 
 
-@pytest.mark.parametrize("world,grid,sorter,side", [(2, (1, 1, 2), 0, 16), (4, (2, 2, 1), 1, 16), (8, (2, 2, 2), 1, 20)])
-def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, side):
-    n, steps = (side, side, side), 60
+@pytest.mark.parametrize("world,grid,sorter,n,overlap", [
+    (2, (1, 1, 2), 0, (16, 16, 16), False), (4, (2, 2, 1), 1, (16, 16, 16), False), (8, (2, 2, 2), 1, (20, 20, 20), False),
+    # sub-boxes long enough along the decomposed axes to have tile blocks that see no ghosts: their forces are
+    # computed on a second stream while the halo exchange runs
+    (2, (1, 1, 2), 1, (10, 10, 36), True), (4, (2, 2, 1), 0, (36, 36, 10), True)])
+def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, overlap):
+    steps = 60
     ref = str(tmp_path / "ref.npz")
     out = str(tmp_path / "dd.npz")
-    launch("_dd_worker.py", 1, list((1, 1, 1)) + [ref] + list(n) + [steps, sorter], timeout=300)
-    launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter], timeout=300)
+    launch("_dd_worker.py", 1, list((1, 1, 1)) + [ref] + list(n) + [steps, sorter], timeout=60)
+    launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter], timeout=60)
     a, b = np.load(ref), np.load(out)
-    assert sum(b["N_local"]) == side**3 and all(g > 0 for g in b["n_ghosts"])
+    assert sum(b["N_local"]) == n[0] * n[1] * n[2] and all(g > 0 for g in b["n_ghosts"])
     assert sum(b["migrated"]) > 0
     # every rank is every other rank's neighbor in these grids: the rebuild vote rode in the halo exchange
     assert min(b["vote_exchanges"]) > 0
+    if overlap:
+        assert min(b["overlapped"]) > steps // 2
+    else:
+        assert max(b["overlapped"]) == 0
     assert np.allclose(a["e0"], b["e0"], rtol=1e-11)
     assert np.allclose(a["e1"], b["e1"], rtol=1e-7)
     assert a["dof"] == b["dof"]
-    L = side * (1 / 0.84) ** (1 / 3)
+    L = np.array(n) * (1 / 0.84) ** (1 / 3)
     ua = a["position"] + a["image"] * L
     ub = b["position"] + b["image"] * L
     assert np.abs(ua - ub).max() < 1e-7

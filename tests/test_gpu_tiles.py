@@ -158,3 +158,33 @@ def test_tile_forces_after_particles_wrap_between_builds(K, A):
         F_tile, V_tile = K.pair_forces_tiles("lj", pos2_t, N, gbox, tl, P, [[6.25]], compute_virial=True, fast=fast)
         assert _rel_err(F_tile.cpu().numpy(), F_rows.cpu().numpy()) < F_RTOL * 1e-4
         assert _rel_err(V_tile.cpu().numpy(), V_rows.cpu().numpy()) < F_RTOL * 1e-4
+
+
+@pytest.mark.parametrize("fast,wlo,whi", [(False, (1, 0, 1), (-2, -1, -1)), (True, (1, 0, 1), (-2, -1, -1)), (True, (0, 1, 0), (-1, -2, -2)),
+                                          (True, (1, 1, 1), (1, 1, 1))])
+def test_tile_forces_by_block_window(K, A, fast, wlo, whi):
+    """The blocks inside a window plus the blocks outside it give, bit for bit, what one launch over all
+    blocks gives; each launch writes only the particles of its own blocks."""
+    xyz, typ, L = liquid(20, seed=5)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos_t = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
+    tl, _, dim = tile_nlist(K, A, pos_t, N, gbox, obox, [[2.5]], 0.4)
+    nb = [(d + 1) // 2 for d in dim]
+    assert min(nb) >= 3
+    P = [orc.lj_params(1.0, 1.0)]
+    F_all, V_all = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=True, fast=fast)
+    lo, hi = wlo, tuple(h if h > 0 else nb[d] + h for d, h in enumerate(whi))
+    F_in, V_in = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=True, fast=fast, window=(1, lo, hi))
+    written = ~torch.isnan(F_in[:, 0])
+    assert 0 < int(written.sum()) < N
+    assert torch.equal(F_in[written], F_all[written])
+    F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=True, fast=fast, window=(2, lo, hi), into=(F_in.clone(), V_in.clone()))
+    assert torch.equal(F, F_all) and torch.equal(V, V_all)
+    # the outside launch alone leaves the inside particles untouched
+    F_out, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], compute_virial=False, fast=fast, window=(2, lo, hi))
+    assert torch.equal(torch.isnan(F_out[:, 0]), written)
+    with pytest.raises(A.KernelError, match="window"):
+        K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], window=(1, (0, 0, 0), (nb[0], 0, 0)))
+    with pytest.raises(A.KernelError, match="block_window_mode"):
+        K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], window=(3, (0, 0, 0), (0, 0, 0)))
