@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(256) migrate_dest_kernel(hmd_migrate_dest_args
     {
     const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool leaves = false;
+    unsigned int dest = a.rank;
     if (idx < a.N)
         {
         const double4 p = hmd_ld4(a.d_pos + idx);
@@ -115,13 +116,161 @@ __global__ void __launch_bounds__(256) migrate_dest_kernel(hmd_migrate_dest_args
             const long long gi = (long long)g;
             c[d] = (unsigned int)min(max(gi, 0ll), (long long)a.grid[d] - 1);
             }
-        const unsigned int dest = (c[2] * a.grid[1] + c[1]) * a.grid[0] + c[0];
+        dest = (c[2] * a.grid[1] + c[1]) * a.grid[0] + c[0];
         a.d_dest[idx] = (int)dest;
         leaves = dest != a.rank;
         }
     const unsigned long long m = __ballot(leaves);
-    if (m && (threadIdx.x & 63) == 0)
-        atomicAdd(a.d_n_leave, (unsigned int)__popcll(m));
+    if (!m)
+        return;
+    // one reservation per wave
+    unsigned int base = 0;
+    if ((threadIdx.x & 63) == 0)
+        base = atomicAdd(a.d_n_leave, (unsigned int)__popcll(m));
+    if (a.d_keys)
+        {
+        base = __shfl(base, 0, 64);
+        if (leaves)
+            {
+            const unsigned int slot = base + hmd_rank_in_mask(m);
+            if (slot < a.capacity)
+                a.d_keys[slot] = ((unsigned long long)dest << 32) | idx;
+            atomicAdd(a.d_rank_count + dest, 1u);
+            }
+        }
+    }
+
+__device__ __forceinline__ long long bits_of(double v)
+    {
+    return __double_as_longlong(v);
+    }
+
+__global__ void __launch_bounds__(256) migrate_pack_kernel(hmd_migrate_pack_args_t a)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n)
+        return;
+    const unsigned int i = (unsigned int)(a.d_keys[k] & 0xffffffffull);
+    const double4 p = hmd_ld4(a.arrays.d_pos + i);
+    const double4 v = hmd_ld4(a.arrays.d_vel + i);
+    const hmd_scalar3 acc = a.arrays.d_accel[i];
+    const hmd_int3 img = a.arrays.d_image[i];
+    double x[3] = {p.x, p.y, p.z};
+    long long im[3] = {img.x, img.y, img.z};
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+        {
+        // the wrap the owner decision used (migrate_dest_kernel): same arithmetic, same result
+        const double f = HMD_SUB(x[d], a.global_lo[d]) / a.global_L[d];
+        const double w = a.decomposed[d] ? floor(f) : 0.0;
+        x[d] = HMD_SUB(x[d], HMD_MUL(w, a.global_L[d]));
+        im[d] += (long long)w;
+        }
+    long long* row = a.d_out + (size_t)k * HMD_MIGRATE_ROW_WORDS;
+    row[0] = bits_of(x[0]);
+    row[1] = bits_of(x[1]);
+    row[2] = bits_of(x[2]);
+    row[3] = bits_of(p.w);
+    row[4] = bits_of(v.x);
+    row[5] = bits_of(v.y);
+    row[6] = bits_of(v.z);
+    row[7] = bits_of(v.w);
+    row[8] = bits_of(acc.x);
+    row[9] = bits_of(acc.y);
+    row[10] = bits_of(acc.z);
+    row[11] = im[0];
+    row[12] = im[1];
+    row[13] = im[2];
+    row[14] = (long long)(int)a.arrays.d_tag[i];
+    row[15] = (long long)(int)a.arrays.d_body[i];
+    row[16] = bits_of(a.arrays.d_charge[i]);
+    row[17] = bits_of(a.arrays.d_diameter[i]);
+    }
+
+__global__ void __launch_bounds__(256) migrate_unpack_kernel(hmd_migrate_unpack_args_t a)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n)
+        return;
+    const long long* row = a.d_in + (size_t)k * HMD_MIGRATE_ROW_WORDS;
+    const unsigned int i = a.first + k;
+    hmd_st4(a.arrays.d_pos + i, __longlong_as_double(row[0]), __longlong_as_double(row[1]), __longlong_as_double(row[2]), __longlong_as_double(row[3]));
+    hmd_st4(a.arrays.d_vel + i, __longlong_as_double(row[4]), __longlong_as_double(row[5]), __longlong_as_double(row[6]), __longlong_as_double(row[7]));
+    hmd_scalar3 acc;
+    acc.x = __longlong_as_double(row[8]);
+    acc.y = __longlong_as_double(row[9]);
+    acc.z = __longlong_as_double(row[10]);
+    a.arrays.d_accel[i] = acc;
+    hmd_int3 img;
+    img.x = (int)row[11];
+    img.y = (int)row[12];
+    img.z = (int)row[13];
+    a.arrays.d_image[i] = img;
+    a.arrays.d_tag[i] = (unsigned int)row[14];
+    a.arrays.d_body[i] = (unsigned int)row[15];
+    a.arrays.d_charge[i] = __longlong_as_double(row[16]);
+    a.arrays.d_diameter[i] = __longlong_as_double(row[17]);
+    }
+
+constexpr unsigned int MF_THREADS = 1024;
+
+// Appends value(j) for every j < n with flag(j) to `out` in order of j; returns how many.  One workgroup.
+template<class Flag, class Value>
+__device__ unsigned int block_compact(unsigned int n, unsigned int* out, unsigned int* s_wave, Flag flag, Value value)
+    {
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int base = 0;
+    for (unsigned int j0 = 0; j0 < n; j0 += MF_THREADS)
+        {
+        const unsigned int j = j0 + threadIdx.x;
+        const bool f = j < n && flag(j);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0)
+            s_wave[wave] = (unsigned int)__popcll(m);
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+        for (unsigned int w = 0; w < MF_THREADS / 64; w++)
+            {
+            const unsigned int c = s_wave[w];
+            before += w < wave ? c : 0u;
+            total += c;
+            }
+        if (f)
+            out[base + before + hmd_rank_in_mask(m)] = value(j);
+        base += total;
+        __syncthreads();
+        }
+    return base;
+    }
+
+__global__ void __launch_bounds__(MF_THREADS) migrate_fill_kernel(hmd_migrate_fill_args_t a)
+    {
+    __shared__ unsigned int s_wave[MF_THREADS / 64];
+    const unsigned int n_keep = a.N - a.n_leave;
+    unsigned int* holes = a.d_scratch;
+    unsigned int* movers = a.d_scratch + a.n_leave;
+    // places in front of the boundary that a leaver frees, in the order of the (sorted) keys
+    const unsigned int nh = block_compact(
+        a.n_leave, holes, s_wave, [&](unsigned int j) { return (unsigned int)(a.d_keys[j] & 0xffffffffull) < n_keep; },
+        [&](unsigned int j) { return (unsigned int)(a.d_keys[j] & 0xffffffffull); });
+    // stayers behind the boundary, in index order
+    block_compact(
+        a.n_leave, movers, s_wave, [&](unsigned int j) { return a.d_dest[n_keep + j] == (int)a.rank; }, [&](unsigned int j) { return n_keep + j; });
+    __syncthreads(); // (the lists live in global memory: written and read by this one workgroup)
+    for (unsigned int k = threadIdx.x; k < nh; k += MF_THREADS)
+        {
+        const unsigned int src = movers[k], dst = holes[k];
+        const double4 p = hmd_ld4(a.arrays.d_pos + src);
+        hmd_st4(a.arrays.d_pos + dst, p.x, p.y, p.z, p.w);
+        const double4 v = hmd_ld4(a.arrays.d_vel + src);
+        hmd_st4(a.arrays.d_vel + dst, v.x, v.y, v.z, v.w);
+        a.arrays.d_accel[dst] = a.arrays.d_accel[src];
+        a.arrays.d_image[dst] = a.arrays.d_image[src];
+        a.arrays.d_tag[dst] = a.arrays.d_tag[src];
+        a.arrays.d_body[dst] = a.arrays.d_body[src];
+        a.arrays.d_charge[dst] = a.arrays.d_charge[src];
+        a.arrays.d_diameter[dst] = a.arrays.d_diameter[src];
+        }
     }
 
 __global__ void __launch_bounds__(256) pack_pos_kernel(hmd_pack_pos_args_t a)
@@ -223,6 +372,8 @@ extern "C" int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* strea
     for (int d = 0; d < 3; d++)
         HMD_REQUIRE(args->grid[d] >= 1 && args->global_L[d] > 0.0, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: empty grid or box");
     HMD_REQUIRE(args->rank < args->grid[0] * args->grid[1] * args->grid[2], HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_dest: rank outside the grid");
+    HMD_REQUIRE(!args->d_keys || (args->d_rank_count && args->n_ranks == args->grid[0] * args->grid[1] * args->grid[2]), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_dest: d_keys needs d_rank_count with one entry per rank of the grid");
     if (args->N == 0)
         return HMD_OK;
     hipLaunchKernelGGL(migrate_dest_kernel, dim3(hmd_div_up(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
@@ -237,5 +388,45 @@ extern "C" int hmd_pack_ghost_positions(const hmd_pack_pos_args_t* args, void* s
     if (args->n_send == 0)
         return HMD_OK;
     hipLaunchKernelGGL(pack_pos_kernel, dim3(hmd_div_up(args->n_send, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+static bool pdata_arrays_complete(const hmd_pdata_arrays_t& p)
+    {
+    return p.d_pos && p.d_vel && p.d_accel && p.d_image && p.d_tag && p.d_body && p.d_charge && p.d_diameter;
+    }
+
+extern "C" int hmd_migrate_pack(const hmd_migrate_pack_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack: args is NULL");
+    if (args->n == 0)
+        return HMD_OK;
+    HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_keys && args->d_out, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_pack: all particle arrays, d_keys and d_out are required");
+    for (int d = 0; d < 3; d++)
+        HMD_REQUIRE(args->global_L[d] > 0.0, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack: empty box");
+    hipLaunchKernelGGL(migrate_pack_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_migrate_fill(const hmd_migrate_fill_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_fill: args is NULL");
+    if (args->n_leave == 0)
+        return HMD_OK;
+    HMD_REQUIRE(args->n_leave <= args->N, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_fill: more leavers than particles");
+    HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_dest && args->d_keys && args->d_scratch, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_fill: all particle arrays, d_dest, d_keys and d_scratch are required");
+    hipLaunchKernelGGL(migrate_fill_kernel, dim3(1), dim3(MF_THREADS), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_unpack: args is NULL");
+    if (args->n == 0)
+        return HMD_OK;
+    HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_in, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_unpack: all particle arrays and d_in are required");
+    hipLaunchKernelGGL(migrate_unpack_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }

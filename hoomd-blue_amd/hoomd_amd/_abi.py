@@ -161,7 +161,30 @@ class GhostPlanArgs(C.Structure):
 
 class MigrateDestArgs(C.Structure):
     _fields_ = [("d_pos", vp), ("N", u32), ("global_lo", f64 * 3), ("global_L", f64 * 3), ("grid", u32 * 3),
-                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("rank", u32), ("d_dest", vp), ("d_n_leave", vp)]
+                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("rank", u32), ("d_dest", vp), ("d_n_leave", vp),
+                ("d_keys", vp), ("capacity", u32), ("d_rank_count", vp), ("n_ranks", u32)]
+
+
+class PDataArraysStruct(C.Structure):
+    _fields_ = [("d_pos", vp), ("d_vel", vp), ("d_accel", vp), ("d_image", vp), ("d_tag", vp), ("d_body", vp),
+                ("d_charge", vp), ("d_diameter", vp)]
+
+
+MIGRATE_ROW_WORDS = 18
+
+
+class MigratePackArgs(C.Structure):
+    _fields_ = [("arrays", PDataArraysStruct), ("d_keys", vp), ("n", u32), ("global_lo", f64 * 3), ("global_L", f64 * 3),
+                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("d_out", vp)]
+
+
+class MigrateFillArgs(C.Structure):
+    _fields_ = [("arrays", PDataArraysStruct), ("d_dest", vp), ("rank", u32), ("N", u32), ("d_keys", vp), ("n_leave", u32),
+                ("d_scratch", vp)]
+
+
+class MigrateUnpackArgs(C.Structure):
+    _fields_ = [("arrays", PDataArraysStruct), ("d_in", vp), ("first", u32), ("n", u32)]
 
 
 class GhostSendListArgs(C.Structure):
@@ -221,6 +244,9 @@ _SIGNATURES = {
     "hmd_unpack_ghost_positions": (C.c_int, [C.POINTER(UnpackVoteArgs), vp]),
     "hmd_ghost_send_list": (C.c_int, [C.POINTER(GhostSendListArgs), vp]),
     "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
+    "hmd_migrate_pack": (C.c_int, [C.POINTER(MigratePackArgs), vp]),
+    "hmd_migrate_fill": (C.c_int, [C.POINTER(MigrateFillArgs), vp]),
+    "hmd_migrate_unpack": (C.c_int, [C.POINTER(MigrateUnpackArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_publish_words": (C.c_int, [vp, u32, vp, u32, vp]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),

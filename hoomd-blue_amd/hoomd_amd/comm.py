@@ -316,7 +316,11 @@ class ParticleExchange:
         self.n_migrated_out = 0
         self.n_migrated_in = 0
         self._vote = None
-        self._n_leave = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._mig_dest = None
+        self._mig_counters = None
+        self._mig_keys = None
+        self._mig_empty = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
+        self._mig_empty_in = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
         self._r_ghost = None
         self._r_ghost_value = None
         self.vote_plan = None
@@ -344,34 +348,88 @@ class ParticleExchange:
 
     # ---- migration (hoomd/Communicator.cc migrateParticles) ----
     def migrate(self):
+        if self.device.type == "cuda":
+            return self._migrate_kernels()
+        return self._migrate_tensor_ops()
+
+    def _pdata_struct(self):
+        A, m = self.arrays, _abi()
+        p = m.PDataArraysStruct()
+        p.d_pos, p.d_vel, p.d_accel, p.d_image = A.pos.data_ptr(), A.vel.data_ptr(), A.accel.data_ptr(), A.image.data_ptr()
+        p.d_tag, p.d_body, p.d_charge, p.d_diameter = A.tag.data_ptr(), A.body.data_ptr(), A.charge.data_ptr(), A.diameter.data_ptr()
+        return p
+
+    def _migrate_kernels(self):
+        """Migration with one kernel per stage: owners + leaver keys + counts per owner, one readback, a sort
+        of the (few) keys, pack, the two collectives, gap filling, unpack."""
+        A, dd, m = self.arrays, self.dd, _abi()
+        N = A.N
+        A.set_n_ghosts(0)  # ghosts are re-exchanged afterwards
+        world = dd.world
+        if self._mig_dest is None or self._mig_dest.numel() < max(N, 1):
+            self._mig_dest = torch.empty(int(max(N, 1) * 1.125) + 64, dtype=torch.int32, device=self.device)
+        if self._mig_counters is None:
+            self._mig_counters = torch.zeros(1 + world, dtype=torch.int32, device=self.device)
+            self._mig_keys = torch.empty(4096, dtype=torch.int64, device=self.device)
+        a = m.MigrateDestArgs()
+        a.d_pos, a.N, a.rank = A.pos.data_ptr(), N, dd.rank
+        a.global_lo[:], a.global_L[:], a.grid[:] = list(dd.glo), list(dd.gL), list(dd.grid)
+        a.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
+        a.d_dest = self._mig_dest.data_ptr()
+        a.d_n_leave, a.d_rank_count, a.n_ranks = self._mig_counters.data_ptr(), self._mig_counters.data_ptr() + 4, world
+        while True:
+            self._mig_counters.zero_()
+            a.d_keys, a.capacity = self._mig_keys.data_ptr(), int(self._mig_keys.numel())
+            m.check(m.lib.hmd_migrate_dest(ctypes.byref(a), None), "hmd_migrate_dest")
+            counters = self._mig_counters.tolist()
+            if counters[0] <= self._mig_keys.numel():
+                break
+            self._mig_keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
+        n_leave, send_counts = counters[0], counters[1:]
+        keys = None
+        payload = self._mig_empty
+        if n_leave:
+            keys, _ = torch.sort(self._mig_keys[:n_leave])
+            payload = torch.empty((n_leave, _ELEM), dtype=torch.int64, device=self.device)
+            pk = m.MigratePackArgs()
+            pk.arrays, pk.d_keys, pk.n, pk.d_out = self._pdata_struct(), keys.data_ptr(), n_leave, payload.data_ptr()
+            pk.global_lo[:], pk.global_L[:] = list(dd.glo), list(dd.gL)
+            pk.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
+            m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
+        recv_counts = self._exchange_counts(send_counts)
+        n_recv = sum(recv_counts)
+        self.n_migrated_out += n_leave
+        self.n_migrated_in += n_recv
+        # every rank takes part in the collective, also with nothing to send or receive
+        incoming = torch.empty((n_recv, _ELEM), dtype=torch.int64, device=self.device) if n_recv else self._mig_empty_in
+        self._a2a(incoming, payload, recv_counts, send_counts)
+        if n_leave == 0 and n_recv == 0:
+            return False
+        n_keep = N - n_leave
+        if n_leave:
+            scratch = torch.empty(2 * n_leave, dtype=torch.int32, device=self.device)
+            f = m.MigrateFillArgs()
+            f.arrays, f.d_dest, f.rank, f.N = self._pdata_struct(), self._mig_dest.data_ptr(), dd.rank, N
+            f.d_keys, f.n_leave, f.d_scratch = keys.data_ptr(), n_leave, scratch.data_ptr()
+            m.check(m.lib.hmd_migrate_fill(ctypes.byref(f), None), "hmd_migrate_fill")
+        A.resize_owned(n_keep + n_recv)  # (keeps the contents when it has to reallocate)
+        if n_recv:
+            u = m.MigrateUnpackArgs()
+            u.arrays, u.d_in, u.first, u.n = self._pdata_struct(), incoming.data_ptr(), n_keep, n_recv
+            m.check(m.lib.hmd_migrate_unpack(ctypes.byref(u), None), "hmd_migrate_unpack")
+        return True
+
+    def _migrate_tensor_ops(self):
         A, dd = self.arrays, self.dd
         N = A.N
         A.set_n_ghosts(0)  # ghosts are re-exchanged afterwards
-        wrap = None
-        if self.device.type == "cuda":
-            # one kernel decides every particle's owner and counts the leavers; nothing else runs when none leaves
-            dest = torch.empty(max(N, 1), dtype=torch.int32, device=self.device)[:N]
-            self._n_leave.zero_()
-            a = _abi().MigrateDestArgs()
-            a.d_pos, a.N, a.rank = A.pos.data_ptr(), N, dd.rank
-            a.global_lo[:], a.global_L[:], a.grid[:] = list(dd.glo), list(dd.gL), list(dd.grid)
-            a.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
-            a.d_dest, a.d_n_leave = dest.data_ptr(), self._n_leave.data_ptr()
-            _abi().check(_abi().lib.hmd_migrate_dest(ctypes.byref(a), None), "hmd_migrate_dest")
-            if int(self._n_leave.item()):
-                leave = dest != dd.rank
-                li = torch.nonzero(leave).flatten()
-            else:
-                leave = None
-                li = torch.zeros(0, dtype=torch.int64, device=self.device)
-        else:
-            x = A.pos[:N, :3]
-            f = (x - self.glo) / self.gL
-            wrap = torch.where(self.dec, torch.floor(f), torch.zeros_like(f))
-            c = torch.clamp(torch.floor((f - wrap) * self.gridf).to(torch.int64), min=torch.zeros_like(self.gridi), max=self.gridi - 1)
-            dest = (c[:, 2] * dd.grid[1] + c[:, 1]) * dd.grid[0] + c[:, 0]
-            leave = dest != dd.rank
-            li = torch.nonzero(leave).flatten()
+        x = A.pos[:N, :3]
+        f = (x - self.glo) / self.gL
+        wrap = torch.where(self.dec, torch.floor(f), torch.zeros_like(f))
+        c = torch.clamp(torch.floor((f - wrap) * self.gridf).to(torch.int64), min=torch.zeros_like(self.gridi), max=self.gridi - 1)
+        dest = (c[:, 2] * dd.grid[1] + c[:, 1]) * dd.grid[0] + c[:, 0]
+        leave = dest != dd.rank
+        li = torch.nonzero(leave).flatten()
         n_leave = int(li.numel())
         send_counts = [0] * dd.world
         payload = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
@@ -379,11 +437,7 @@ class ParticleExchange:
             dl, order = torch.sort(dest[li].to(torch.int64), stable=True)
             li = li[order]
             send_counts = torch.bincount(dl, minlength=dd.world).tolist()
-            if wrap is not None:
-                w = wrap[li]
-            else:
-                fl = (A.pos[li, :3] - self.glo) / self.gL
-                w = torch.where(self.dec, torch.floor(fl), torch.zeros_like(fl))
+            w = wrap[li]
             p = A.pos[li].clone()
             p[:, :3] -= w * self.gL
             img = A.image[li].to(torch.int64) + w.to(torch.int64)
@@ -400,7 +454,7 @@ class ParticleExchange:
         self._a2a(incoming, payload, recv_counts, send_counts)
         if n_leave == 0 and n_recv == 0:
             return False
-        keep = torch.nonzero(~leave).flatten() if leave is not None else torch.arange(N, dtype=torch.int64, device=self.device)
+        keep = torch.nonzero(~leave).flatten()
         n_keep = int(keep.numel())
         new_n = n_keep + n_recv
         kept = {name: getattr(A, name)[keep] for name in HostArrays._PER_PARTICLE} if n_leave else None

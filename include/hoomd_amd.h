@@ -635,8 +635,76 @@ typedef struct
     unsigned int rank;
     int* d_dest;
     unsigned int* d_n_leave;
+    /* Optional, all or none: the leavers as keys (owner << 32 | particle index) appended to d_keys in no
+       particular order (sorted, they are the send list ordered by owner, then index; keys beyond `capacity`
+       are dropped, *d_n_leave still counts them) and their number per owner in d_rank_count[n_ranks]
+       (the caller zeroes it). */
+    unsigned long long* d_keys;
+    unsigned int capacity;
+    unsigned int* d_rank_count;
+    unsigned int n_ranks;
     } hmd_migrate_dest_args_t;
 int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* stream);
+
+/* The per-particle arrays a migrating particle takes along (pdata_element, hoomd/ParticleData.h:153-175). */
+typedef struct
+    {
+    hmd_scalar4* d_pos;
+    hmd_scalar4* d_vel;
+    hmd_scalar3* d_accel;
+    hmd_int3* d_image;
+    unsigned int* d_tag;
+    unsigned int* d_body;
+    double* d_charge;
+    double* d_diameter;
+    } hmd_pdata_arrays_t;
+#define HMD_MIGRATE_ROW_WORDS 18 /* 64-bit words per particle in a migration message */
+
+/* Pack the leavers into message rows (the role of gpu_pack / ParticleData::removeParticlesGPU's output,
+   hoomd/ParticleData.cu:60-190, hoomd/CommunicatorGPU.cu:60-170): row k holds the particle of d_keys[k]
+   (low 32 bits = index) as 18 words: pos.xyzw, vel.xyzw, accel.xyz (bit patterns of the doubles), image.xyz,
+   tag, body (as signed 64-bit integers), charge, diameter (bit patterns).  The position is wrapped into the
+   global box along decomposed directions and the image adjusted (hoomd/Communicator.cc:1189-1220). */
+typedef struct
+    {
+    hmd_pdata_arrays_t arrays;
+    const unsigned long long* d_keys;
+    unsigned int n;
+    double global_lo[3];
+    double global_L[3];
+    unsigned char decomposed[3];
+    unsigned char pad_;
+    long long* d_out;
+    } hmd_migrate_pack_args_t;
+int hmd_migrate_pack(const hmd_migrate_pack_args_t* args, void* stream);
+
+/* Close the gaps the leavers leave: the N - n_leave staying particles end up in [0, N - n_leave).  Stayers
+   behind that boundary move into the leavers' places in front of it (in the order of d_keys, which must be
+   sorted); everything else stays where it is.  d_dest: owner per particle as hmd_migrate_dest wrote it;
+   d_scratch: 2 * n_leave words.  Stands in for the compaction of ParticleData::removeParticlesGPU
+   (hoomd/ParticleData.cu:120-190), which keeps the order of the stayers instead. */
+typedef struct
+    {
+    hmd_pdata_arrays_t arrays;
+    const int* d_dest;
+    unsigned int rank;
+    unsigned int N;
+    const unsigned long long* d_keys;
+    unsigned int n_leave;
+    unsigned int* d_scratch;
+    } hmd_migrate_fill_args_t;
+int hmd_migrate_fill(const hmd_migrate_fill_args_t* args, void* stream);
+
+/* Append received message rows to the arrays: row k becomes particle first + k
+   (ParticleData::addParticlesGPU, hoomd/ParticleData.cu:200-260). */
+typedef struct
+    {
+    hmd_pdata_arrays_t arrays;
+    const long long* d_in;
+    unsigned int first;
+    unsigned int n;
+    } hmd_migrate_unpack_args_t;
+int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Tile path: the same neighbor list and pair forces, laid out for LDS instead of L1 gathers.

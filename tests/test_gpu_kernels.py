@@ -695,3 +695,110 @@ def test_ghost_send_list_keys(K, A):
         assert c[1:] == [int(((want_plan & m) == m).sum()) for m in masks]
     assert np.array_equal(plan.cpu().numpy(), want_plan)
     assert sorted(keys[:len(want)].tolist()) == want and int(keys[len(want)]) == -1
+
+
+@pytest.mark.parametrize("N,frac_out", [(5000, 0.03), (3000, 0.6), (700, 0.0)])
+def test_migration_kernels(K, A, N, frac_out):
+    """Owner keys + counts, pack, gap filling and unpack against the same steps done with array operations
+    (the expressions of the CPU-tensor path of ParticleExchange.migrate)."""
+    import ctypes as C
+    rng = np.random.default_rng(5 + N)
+    glo, gL, grid, dec, rank = np.array([-6.0, -7.0, -8.0]), np.array([12.0, 14.0, 16.0]), (2, 1, 3), (1, 0, 1), 3
+    world = 6
+    lo = glo + np.array([1, 0, 1]) * gL / np.array(grid)     # rank 3 = cell (1, 0, 1)
+    xyz = lo + rng.random((N, 3)) * gL / np.array(grid)
+    out = rng.random(N) < frac_out
+    xyz[out] += rng.normal(0, 4.0, (int(out.sum()), 3)) * np.array(dec)   # some leave, also across the periodic boundary
+    pos = orc.pack_pos(xyz, rng.integers(0, 3, N))
+    vel, accel = rng.normal(size=(N, 4)), rng.normal(size=(N, 3))
+    image = rng.integers(-3, 4, (N, 3)).astype(np.int32)
+    tag = rng.permutation(N).astype(np.int32)
+    body = np.where(rng.random(N) < 0.5, -1, tag).astype(np.int32)
+    charge, diameter = rng.normal(size=N), rng.random(N) + 0.5
+    host = dict(pos=pos, vel=vel, accel=accel, image=image, tag=tag, body=body, charge=charge, diameter=diameter)
+    extra = 400  # room for incoming particles
+    dev = {}
+    for k, v in host.items():
+        t = torch.zeros((N + extra,) + v.shape[1:], dtype=torch.from_numpy(v).dtype, device="cuda")
+        t[:N] = torch.from_numpy(v).cuda()
+        dev[k] = t
+
+    def arrays():
+        p = A.PDataArraysStruct()
+        p.d_pos, p.d_vel, p.d_accel, p.d_image = dev["pos"].data_ptr(), dev["vel"].data_ptr(), dev["accel"].data_ptr(), dev["image"].data_ptr()
+        p.d_tag, p.d_body, p.d_charge, p.d_diameter = dev["tag"].data_ptr(), dev["body"].data_ptr(), dev["charge"].data_ptr(), dev["diameter"].data_ptr()
+        return p
+
+    # ---- owners, keys and counts per owner ----
+    dest = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    counters = torch.zeros(1 + world, dtype=torch.int32, device="cuda")
+    keys = torch.zeros(N, dtype=torch.int64, device="cuda")
+    a = A.MigrateDestArgs()
+    a.d_pos, a.N, a.rank = dev["pos"].data_ptr(), N, rank
+    a.global_lo[:], a.global_L[:], a.grid[:], a.decomposed[:] = list(glo), list(gL), list(grid), list(dec)
+    a.d_dest, a.d_n_leave, a.d_rank_count, a.n_ranks = dest.data_ptr(), counters.data_ptr(), counters.data_ptr() + 4, world
+    a.d_keys, a.capacity = keys.data_ptr(), N
+    A.check(A.lib.hmd_migrate_dest(C.byref(a), None), "hmd_migrate_dest")
+    f = (xyz - glo) / gL
+    w = np.where(np.array(dec, dtype=bool), np.floor(f), 0.0)
+    c = np.clip(np.floor((f - w) * np.array(grid)).astype(np.int64), 0, np.array(grid) - 1)
+    want_dest = (c[:, 2] * grid[1] + c[:, 1]) * grid[0] + c[:, 0]
+    leave = want_dest != rank
+    n_leave = int(leave.sum())
+    cnt = counters.cpu().numpy()
+    assert np.array_equal(dest.cpu().numpy(), want_dest)
+    assert cnt[0] == n_leave and np.array_equal(cnt[1:], np.bincount(want_dest[leave], minlength=world))
+    skeys = torch.sort(keys[:n_leave])[0]
+    li = np.nonzero(leave)[0]
+    li = li[np.argsort(want_dest[li], kind="stable")]
+    assert np.array_equal(skeys.cpu().numpy(), (want_dest[li].astype(np.int64) << 32) | li)
+    # a key buffer that is too small: the count still says how many there are
+    a.capacity = max(n_leave // 2, 1)
+    counters.zero_()
+    A.check(A.lib.hmd_migrate_dest(C.byref(a), None), "hmd_migrate_dest")
+    assert int(counters[0].item()) == n_leave
+
+    # ---- pack ----
+    payload = torch.full((max(n_leave, 1), A.MIGRATE_ROW_WORDS), -7, dtype=torch.int64, device="cuda")
+    pk = A.MigratePackArgs()
+    pk.arrays, pk.d_keys, pk.n, pk.d_out = arrays(), skeys.data_ptr(), n_leave, payload.data_ptr()
+    pk.global_lo[:], pk.global_L[:], pk.decomposed[:] = list(glo), list(gL), list(dec)
+    A.check(A.lib.hmd_migrate_pack(C.byref(pk), None), "hmd_migrate_pack")
+    p = pos[li].copy()
+    p[:, :3] -= w[li] * gL
+    exp = np.concatenate([p.view(np.int64), vel[li].view(np.int64), accel[li].view(np.int64), image[li].astype(np.int64) + w[li].astype(np.int64),
+                          tag[li].astype(np.int64)[:, None], body[li].astype(np.int64)[:, None], charge[li].view(np.int64)[:, None],
+                          diameter[li].view(np.int64)[:, None]], axis=1)
+    assert np.array_equal(payload.cpu().numpy()[:n_leave], exp)
+
+    # ---- fill the gaps: the stayers, each with all of its fields, end up in [0, n_keep) ----
+    n_keep = N - n_leave
+    scratch = torch.zeros(max(2 * n_leave, 1), dtype=torch.int32, device="cuda")
+    fl = A.MigrateFillArgs()
+    fl.arrays, fl.d_dest, fl.rank, fl.N, fl.d_keys, fl.n_leave, fl.d_scratch = arrays(), dest.data_ptr(), rank, N, skeys.data_ptr(), n_leave, scratch.data_ptr()
+    A.check(A.lib.hmd_migrate_fill(C.byref(fl), None), "hmd_migrate_fill")
+    got = {k: v.cpu().numpy() for k, v in dev.items()}
+    stay = np.nonzero(~leave)[0]
+    assert sorted(got["tag"][:n_keep]) == sorted(tag[stay])
+    by_tag = np.empty(N, dtype=np.int64)
+    by_tag[tag] = np.arange(N)
+    src = by_tag[got["tag"][:n_keep]]
+    for k, v in host.items():
+        assert np.array_equal(got[k][:n_keep], v[src]), k
+    # stayers in front of the boundary did not move
+    front = stay[stay < n_keep]
+    assert np.array_equal(got["tag"][front], tag[front])
+
+    # ---- unpack: the leavers' rows come back as new particles behind the stayers ----
+    n_in = min(n_leave, extra)
+    u = A.MigrateUnpackArgs()
+    u.arrays, u.d_in, u.first, u.n = arrays(), payload.data_ptr(), n_keep, n_in
+    A.check(A.lib.hmd_migrate_unpack(C.byref(u), None), "hmd_migrate_unpack")
+    got = {k: v.cpu().numpy() for k, v in dev.items()}
+    s = slice(n_keep, n_keep + n_in)
+    assert np.array_equal(got["pos"][s].view(np.int64), exp[:n_in, 0:4])
+    assert np.array_equal(got["vel"][s], vel[li[:n_in]]) and np.array_equal(got["accel"][s], accel[li[:n_in]])
+    assert np.array_equal(got["image"][s].astype(np.int64), exp[:n_in, 11:14])
+    assert np.array_equal(got["tag"][s], tag[li[:n_in]]) and np.array_equal(got["body"][s], body[li[:n_in]])
+    assert np.array_equal(got["charge"][s], charge[li[:n_in]]) and np.array_equal(got["diameter"][s], diameter[li[:n_in]])
+    assert A.lib.hmd_migrate_pack(None, None) == A.ERR_INVALID_ARGUMENT
