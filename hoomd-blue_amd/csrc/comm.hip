@@ -7,6 +7,8 @@
 #pragma clang fp contract(off)
 #include "common.cuh"
 
+#include <algorithm>
+
 namespace
     {
 __global__ void __launch_bounds__(256) ghost_plan_kernel(hmd_ghost_plan_args_t a)
@@ -210,6 +212,80 @@ __global__ void __launch_bounds__(256) migrate_unpack_kernel(hmd_migrate_unpack_
     a.arrays.d_body[i] = (unsigned int)row[15];
     a.arrays.d_charge[i] = __longlong_as_double(row[16]);
     a.arrays.d_diameter[i] = __longlong_as_double(row[17]);
+    }
+
+__global__ void __launch_bounds__(256) split_keys_kernel(const unsigned long long* d_keys, unsigned int n, unsigned int* d_send_idx, unsigned char* d_send_dir)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const unsigned long long key = d_keys[k];
+    d_send_idx[k] = (unsigned int)(key & 0xffffffffull);
+    d_send_dir[k] = (unsigned char)(key >> 32);
+    }
+
+__global__ void __launch_bounds__(256) pack_init_kernel(hmd_pack_pos_args_t a, const unsigned int* d_tag)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_send)
+        return;
+    const unsigned int i = a.d_send_idx[k];
+    const double4 p = hmd_ld4(a.d_pos + i);
+    const hmd_scalar3 sh = a.d_shift_table[a.d_send_shift_id[k]];
+    const double w = __hiloint2double((int)d_tag[i], (int)hmd_double_as_uint(p.w));
+    hmd_st4(a.d_out + k, HMD_ADD(p.x, sh.x), HMD_ADD(p.y, sh.y), HMD_ADD(p.z, sh.z), w);
+    }
+
+__global__ void __launch_bounds__(256) unpack_init_kernel(hmd_unpack_ghost_init_args_t a)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n)
+        return;
+    const double4 p = hmd_ld4(a.d_in + k);
+    const unsigned int i = a.first + k;
+    hmd_st4(a.arrays.d_pos + i, p.x, p.y, p.z, hmd_uint_as_double(hmd_double_as_uint(p.w)));
+    a.arrays.d_tag[i] = (unsigned int)__double2hiint(p.w);
+    hmd_int3 zero;
+    zero.x = zero.y = zero.z = 0;
+    a.arrays.d_image[i] = zero;
+    a.arrays.d_body[i] = 0xffffffffu;
+    a.arrays.d_charge[i] = 0.0;
+    a.arrays.d_diameter[i] = 1.0;
+    }
+
+__global__ void __launch_bounds__(256) vote_plan_kernel(hmd_vote_plan_args_t a)
+    {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n_send = a.send_off[a.n_ranks], n_recv = a.recv_off[a.n_ranks];
+    // rows of the outgoing buffer: message to rank r starts after the data rows of the ranks before it and
+    // one vote row for each of those that is not this rank
+    if (t < n_send)
+        {
+        unsigned int r = 0;
+        while (a.send_off[r + 1] <= t)
+            r++;
+        a.d_out_row[t] = t + r - (r > a.rank ? 1u : 0u);
+        }
+    if (t < a.n_ranks && t != a.rank)
+        {
+        const unsigned int j = t - (t > a.rank ? 1u : 0u);
+        a.d_flag_rows[j] = a.send_off[t + 1] + j;
+        }
+    const unsigned int n_in = n_recv + a.n_ranks - 1;
+    if (t < n_in)
+        {
+        // incoming row t: find the rank whose message holds it
+        unsigned int r = 0;
+        for (;; r++)
+            {
+            const unsigned int end = a.recv_off[r + 1] + (r + 1) - ((r + 1) > a.rank ? 1u : 0u); // rows of the messages of ranks <= r
+            if (t < end)
+                break;
+            }
+        const unsigned int begin = a.recv_off[r] + r - (r > a.rank ? 1u : 0u);
+        const unsigned int local = t - begin;
+        a.d_in_map[t] = local < a.recv_off[r + 1] - a.recv_off[r] ? (int)(a.recv_off[r] + local) : -1;
+        }
     }
 
 constexpr unsigned int MF_THREADS = 1024;
@@ -428,5 +504,52 @@ extern "C" int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* s
         return HMD_OK;
     HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_in, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_unpack: all particle arrays and d_in are required");
     hipLaunchKernelGGL(migrate_unpack_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_ghost_split_keys(const unsigned long long* d_keys, unsigned int n, unsigned int* d_send_idx, unsigned char* d_send_dir, void* stream)
+    {
+    if (n == 0)
+        return HMD_OK;
+    HMD_REQUIRE(d_keys && d_send_idx && d_send_dir, HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_split_keys: all arrays are required");
+    hipLaunchKernelGGL(split_keys_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d_keys, n, d_send_idx, d_send_dir);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_pack_ghost_init(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init: args is NULL");
+    if (args->n_send == 0)
+        return HMD_OK;
+    HMD_REQUIRE(args->d_out && args->d_pos && args->d_send_idx && args->d_send_shift_id && args->d_shift_table && d_tag, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_init: all array arguments are required");
+    hipLaunchKernelGGL(pack_init_kernel, dim3(hmd_div_up(args->n_send, 256)), dim3(256), 0, (hipStream_t)stream, *args, d_tag);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_unpack_ghost_init(const hmd_unpack_ghost_init_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_unpack_ghost_init: args is NULL");
+    if (args->n == 0)
+        return HMD_OK;
+    const hmd_pdata_arrays_t& p = args->arrays;
+    HMD_REQUIRE(args->d_in && p.d_pos && p.d_image && p.d_tag && p.d_body && p.d_charge && p.d_diameter, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_unpack_ghost_init: d_in and the pos, image, tag, body, charge and diameter arrays are required");
+    hipLaunchKernelGGL(unpack_init_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_vote_plan(const hmd_vote_plan_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_vote_plan: args is NULL");
+    HMD_REQUIRE(args->n_ranks >= 2 && args->n_ranks <= HMD_VOTE_PLAN_MAX_RANKS && args->rank < args->n_ranks, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_vote_plan: between 2 and 64 ranks");
+    for (unsigned int r = 0; r < args->n_ranks; r++)
+        HMD_REQUIRE(args->send_off[r] <= args->send_off[r + 1] && args->recv_off[r] <= args->recv_off[r + 1], HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_vote_plan: offsets must not decrease");
+    HMD_REQUIRE(args->send_off[0] == 0 && args->recv_off[0] == 0, HMD_ERR_INVALID_ARGUMENT, "hmd_vote_plan: offsets start at 0");
+    HMD_REQUIRE(args->d_out_row && args->d_flag_rows && args->d_in_map, HMD_ERR_INVALID_ARGUMENT, "hmd_vote_plan: all outputs are required");
+    const unsigned int n = std::max(std::max(args->send_off[args->n_ranks], args->recv_off[args->n_ranks] + args->n_ranks - 1), args->n_ranks);
+    hipLaunchKernelGGL(vote_plan_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }

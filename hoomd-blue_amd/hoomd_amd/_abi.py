@@ -183,6 +183,18 @@ class MigrateFillArgs(C.Structure):
                 ("d_scratch", vp)]
 
 
+class UnpackGhostInitArgs(C.Structure):
+    _fields_ = [("d_in", vp), ("n", u32), ("first", u32), ("arrays", PDataArraysStruct)]
+
+
+VOTE_PLAN_MAX_RANKS = 64
+
+
+class VotePlanArgs(C.Structure):
+    _fields_ = [("n_ranks", u32), ("rank", u32), ("send_off", u32 * (VOTE_PLAN_MAX_RANKS + 1)), ("recv_off", u32 * (VOTE_PLAN_MAX_RANKS + 1)),
+                ("d_out_row", vp), ("d_flag_rows", vp), ("d_in_map", vp)]
+
+
 class MigrateUnpackArgs(C.Structure):
     _fields_ = [("arrays", PDataArraysStruct), ("d_in", vp), ("first", u32), ("n", u32)]
 
@@ -244,6 +256,10 @@ _SIGNATURES = {
     "hmd_unpack_ghost_positions": (C.c_int, [C.POINTER(UnpackVoteArgs), vp]),
     "hmd_ghost_send_list": (C.c_int, [C.POINTER(GhostSendListArgs), vp]),
     "hmd_migrate_dest": (C.c_int, [C.POINTER(MigrateDestArgs), vp]),
+    "hmd_ghost_split_keys": (C.c_int, [vp, u32, vp, vp, vp]),
+    "hmd_pack_ghost_init": (C.c_int, [C.POINTER(PackPosArgs), vp, vp]),
+    "hmd_unpack_ghost_init": (C.c_int, [C.POINTER(UnpackGhostInitArgs), vp]),
+    "hmd_vote_plan": (C.c_int, [C.POINTER(VotePlanArgs), vp]),
     "hmd_migrate_pack": (C.c_int, [C.POINTER(MigratePackArgs), vp]),
     "hmd_migrate_fill": (C.c_int, [C.POINTER(MigrateFillArgs), vp]),
     "hmd_migrate_unpack": (C.c_int, [C.POINTER(MigrateUnpackArgs), vp]),

@@ -329,6 +329,9 @@ class ParticleExchange:
         self.n_vote_exchanges = 0
         self._keys = None
         self._send_counters = None
+        self._send_buf = None
+        self._init_buf = None
+        self._plan_buf = None
         self._stream = None  # HIP stream handle for the per-step exchange kernels (None = the default stream)
 
     # ---- collectives ----
@@ -512,10 +515,12 @@ class ParticleExchange:
                 self._keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
             total, per_dir = counters[0], counters[1:1 + ndir]
             keys, _ = torch.sort(self._keys[:total])
-            self.send_idx = (keys & 0xFFFFFFFF).contiguous()
-            dirs = keys >> 32
-            self.send_dir = dirs.to(torch.uint8).contiguous()
-            self.send_shift = self.shift_table[dirs].contiguous() if ndir else torch.zeros((0, 3), dtype=torch.float64, device=self.device)
+            if self._send_buf is None or self._send_buf[0].numel() < total:
+                cap = int(total * 1.25) + 1024
+                self._send_buf = (torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, dtype=torch.uint8, device=self.device))
+            self.send_idx32, self.send_dir = self._send_buf[0][:total], self._send_buf[1][:total]
+            m.check(m.lib.hmd_ghost_split_keys(keys.data_ptr(), total, self.send_idx32.data_ptr(), self.send_dir.data_ptr(), None), "hmd_ghost_split_keys")
+            self.send_idx = self.send_shift = None  # (only the tensor-operation path uses them)
         else:
             x = A.pos[:N, :3]
             f = (x - self.lo) / (self.hi - self.lo)
@@ -536,7 +541,8 @@ class ParticleExchange:
                 self.send_idx = torch.zeros(0, dtype=torch.int64, device=self.device)
                 self.send_dir = torch.zeros(0, dtype=torch.uint8, device=self.device)
                 self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=self.device)
-        self.send_idx32 = self.send_idx.to(torch.int32)
+        if self.device.type != "cuda":
+            self.send_idx32 = self.send_idx.to(torch.int32)
         send_counts = [0] * dd.world
         for k, n in enumerate(per_dir):
             send_counts[self.dir_dest[k]] += int(n)
@@ -545,12 +551,30 @@ class ParticleExchange:
         n_ghost = sum(self.recv_splits)
         A.set_n_ghosts(n_ghost)
         s = slice(N, N + n_ghost)
-        self._a2a(A.tag[s], A.tag[self.send_idx].contiguous(), self.recv_splits, self.send_splits)
-        A.body[s] = -1
-        A.charge[s] = 0.0
-        A.diameter[s] = 1.0
-        A.image[s] = 0
-        self.update_ghosts()
+        if self.device.type == "cuda":
+            # one message per peer carries position, type and tag; the unpack kernel also sets the fields
+            # that are not communicated
+            m = _abi()
+            n_send = int(self.send_idx32.numel())
+            if self._init_buf is None or self._init_buf[0].shape[0] < n_send or self._init_buf[1].shape[0] < n_ghost:
+                self._init_buf = (torch.empty((int(n_send * 1.25) + 64, 4), dtype=torch.float64, device=self.device),
+                                  torch.empty((int(n_ghost * 1.25) + 64, 4), dtype=torch.float64, device=self.device))
+            out, inc = self._init_buf[0][:n_send], self._init_buf[1][:n_ghost]
+            pa = m.PackPosArgs()
+            pa.d_out, pa.d_pos, pa.d_send_idx, pa.d_send_shift_id = out.data_ptr(), A.pos.data_ptr(), self.send_idx32.data_ptr(), self.send_dir.data_ptr()
+            pa.d_shift_table, pa.n_send = self.shift_table.data_ptr(), n_send
+            m.check(m.lib.hmd_pack_ghost_init(ctypes.byref(pa), A.tag.data_ptr(), None), "hmd_pack_ghost_init")
+            self._a2a(inc, out, self.recv_splits, self.send_splits)
+            u = m.UnpackGhostInitArgs()
+            u.d_in, u.n, u.first, u.arrays = inc.data_ptr(), n_ghost, N, self._pdata_struct()
+            m.check(m.lib.hmd_unpack_ghost_init(ctypes.byref(u), None), "hmd_unpack_ghost_init")
+        else:
+            self._a2a(A.tag[s], A.tag[self.send_idx].contiguous(), self.recv_splits, self.send_splits)
+            A.body[s] = -1
+            A.charge[s] = 0.0
+            A.diameter[s] = 1.0
+            A.image[s] = 0
+            self.update_ghosts()
         self._build_vote_plan(n_ghost)
         A.rtag.fill_(NOT_LOCAL)
         n_all = N + n_ghost
@@ -569,32 +593,34 @@ class ParticleExchange:
         if self.device.type != "cuda" or not peers or sorted(set(self.dir_dest)) != peers:
             return
         send, recv = self.send_splits, self.recv_splits
+        m = _abi()
+        if dd.world > m.VOTE_PLAN_MAX_RANKS:
+            return
         aug_send = [send[r] + (r != dd.rank) for r in range(dd.world)]
         aug_recv = [recv[r] + (r != dd.rank) for r in range(dd.world)]
-        out_row, flag_rows, in_map = [], [], []
-        off = 0
-        for r in range(dd.world):
-            out_row.append(torch.arange(off, off + send[r], dtype=torch.int32))
-            if r != dd.rank:
-                flag_rows.append(off + send[r])
-            off += aug_send[r]
-        ghost = 0
-        for r in range(dd.world):
-            in_map.append(torch.arange(ghost, ghost + recv[r], dtype=torch.int32))
-            if r != dd.rank:
-                in_map.append(torch.full((1,), -1, dtype=torch.int32))
-            ghost += recv[r]
-        assert ghost == n_ghost
+        n_send, n_in, n_out = sum(send), sum(aug_recv), sum(aug_send)
+        assert sum(recv) == n_ghost
         dev = self.device
-        self.vote_plan = dict(
-            aug_send=aug_send, aug_recv=aug_recv, n_out=sum(aug_send), n_in=sum(aug_recv),
-            out_row=torch.cat(out_row).to(dev), flag_rows=torch.tensor(flag_rows, dtype=torch.int32, device=dev),
-            in_map=torch.cat(in_map).to(dev))
-        need_out, need_in = sum(aug_send), sum(aug_recv)
-        if self._vote_out is None or self._vote_out.shape[0] < need_out:
-            self._vote_out = torch.empty((int(need_out * 1.25) + 64, 4), dtype=torch.float64, device=dev)
-        if self._vote_in is None or self._vote_in.shape[0] < need_in:
-            self._vote_in = torch.empty((int(need_in * 1.25) + 64, 4), dtype=torch.float64, device=dev)
+        if self._plan_buf is None or self._plan_buf[0].numel() < n_send or self._plan_buf[2].numel() < n_in:
+            self._plan_buf = (torch.empty(int(n_send * 1.25) + 64, dtype=torch.int32, device=dev),
+                              torch.empty(dd.world, dtype=torch.int32, device=dev),
+                              torch.empty(int(n_in * 1.25) + 64, dtype=torch.int32, device=dev))
+        a = m.VotePlanArgs()
+        a.n_ranks, a.rank = dd.world, dd.rank
+        so = ro = 0
+        for r in range(dd.world):
+            a.send_off[r], a.recv_off[r] = so, ro
+            so += send[r]
+            ro += recv[r]
+        a.send_off[dd.world], a.recv_off[dd.world] = so, ro
+        out_row, flag_rows, in_map = self._plan_buf[0][:n_send], self._plan_buf[1][:dd.world - 1], self._plan_buf[2][:n_in]
+        a.d_out_row, a.d_flag_rows, a.d_in_map = out_row.data_ptr(), flag_rows.data_ptr(), in_map.data_ptr()
+        m.check(m.lib.hmd_vote_plan(ctypes.byref(a), None), "hmd_vote_plan")
+        self.vote_plan = dict(aug_send=aug_send, aug_recv=aug_recv, n_out=n_out, n_in=n_in, out_row=out_row, flag_rows=flag_rows, in_map=in_map)
+        if self._vote_out is None or self._vote_out.shape[0] < n_out:
+            self._vote_out = torch.empty((int(n_out * 1.25) + 64, 4), dtype=torch.float64, device=dev)
+        if self._vote_in is None or self._vote_in.shape[0] < n_in:
+            self._vote_in = torch.empty((int(n_in * 1.25) + 64, 4), dtype=torch.float64, device=dev)
 
     def update_ghosts_with_vote(self, d_flag):
         """Ghost positions and the rebuild vote in one exchange (see _build_vote_plan); afterwards the word at

@@ -618,6 +618,56 @@ typedef struct
     } hmd_unpack_vote_args_t;
 int hmd_unpack_ghost_positions(const hmd_unpack_vote_args_t* args, void* stream);
 
+/* The per-particle arrays a migrating particle takes along (pdata_element, hoomd/ParticleData.h:153-175). */
+typedef struct
+    {
+    hmd_scalar4* d_pos;
+    hmd_scalar4* d_vel;
+    hmd_scalar3* d_accel;
+    hmd_int3* d_image;
+    unsigned int* d_tag;
+    unsigned int* d_body;
+    double* d_charge;
+    double* d_diameter;
+    } hmd_pdata_arrays_t;
+/* Split sorted send-list keys (direction << 32 | particle index, from hmd_ghost_send_list) into the two arrays
+   the pack kernels read: d_send_idx[k] = index, d_send_dir[k] = direction (the selection output of
+   gpu_exchange_ghosts_make_indices, hoomd/CommunicatorGPU.cu:374-520). */
+int hmd_ghost_split_keys(const unsigned long long* d_keys, unsigned int n, unsigned int* d_send_idx, unsigned char* d_send_dir, void* stream);
+
+/* First exchange after a new ghost plan: like hmd_pack_ghost_positions, and the particle's tag rides in the
+   upper half of the w component (whose lower half is the type id), so one message carries what the reference
+   sends as separate tag and position messages (hoomd/CommunicatorGPU.cu:778-875, hoomd/Communicator.cc
+   exchangeGhosts).  hmd_unpack_ghost_init is the receiving side: ghost first + k gets position and type of
+   row k, its tag, and the defaults of the fields that are not communicated (image 0, body none, charge 0,
+   diameter 1). */
+int hmd_pack_ghost_init(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, void* stream);
+typedef struct
+    {
+    const hmd_scalar4* d_in;
+    unsigned int n;
+    unsigned int first;
+    hmd_pdata_arrays_t arrays; /* d_vel and d_accel are not touched and may be NULL */
+    } hmd_unpack_ghost_init_args_t;
+int hmd_unpack_ghost_init(const hmd_unpack_ghost_init_args_t* args, void* stream);
+
+/* Row maps for hmd_pack_ghost_positions_vote / hmd_unpack_ghost_positions from the message sizes: every
+   message to or from another rank gets one extra row (the vote) after its data rows.  send_off / recv_off:
+   exclusive prefix sums of the data rows per rank (n_ranks + 1 entries).  Outputs: d_out_row[send_off[n_ranks]],
+   d_flag_rows[n_ranks - 1] (peers in rank order), d_in_map[recv_off[n_ranks] + n_ranks - 1]. */
+#define HMD_VOTE_PLAN_MAX_RANKS 64
+typedef struct
+    {
+    unsigned int n_ranks;
+    unsigned int rank;
+    unsigned int send_off[HMD_VOTE_PLAN_MAX_RANKS + 1];
+    unsigned int recv_off[HMD_VOTE_PLAN_MAX_RANKS + 1];
+    unsigned int* d_out_row;
+    unsigned int* d_flag_rows;
+    int* d_in_map;
+    } hmd_vote_plan_args_t;
+int hmd_vote_plan(const hmd_vote_plan_args_t* args, void* stream);
+
 /* Owner rank of every owned particle after a move (the decision of gpu_stage_particles /
    gpu_select_particle_migrate, hoomd/CommunicatorGPU.cu:60-170, for a regular grid of domains with
    rank = (k * grid[1] + j) * grid[0] + i): fractional position in the global box, wrapped along
@@ -646,18 +696,6 @@ typedef struct
     } hmd_migrate_dest_args_t;
 int hmd_migrate_dest(const hmd_migrate_dest_args_t* args, void* stream);
 
-/* The per-particle arrays a migrating particle takes along (pdata_element, hoomd/ParticleData.h:153-175). */
-typedef struct
-    {
-    hmd_scalar4* d_pos;
-    hmd_scalar4* d_vel;
-    hmd_scalar3* d_accel;
-    hmd_int3* d_image;
-    unsigned int* d_tag;
-    unsigned int* d_body;
-    double* d_charge;
-    double* d_diameter;
-    } hmd_pdata_arrays_t;
 #define HMD_MIGRATE_ROW_WORDS 18 /* 64-bit words per particle in a migration message */
 
 /* Pack the leavers into message rows (the role of gpu_pack / ParticleData::removeParticlesGPU's output,

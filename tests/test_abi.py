@@ -40,7 +40,8 @@ def test_ctypes_struct_layouts_match_the_header():
         "hmd_thermo_args_t": _abi.ThermoArgs, "hmd_cell_order_args_t": _abi.CellOrderArgs,
         "hmd_ghost_plan_args_t": _abi.GhostPlanArgs, "hmd_pack_pos_args_t": _abi.PackPosArgs,
         "hmd_migrate_dest_args_t": _abi.MigrateDestArgs, "hmd_migrate_pack_args_t": _abi.MigratePackArgs,
-        "hmd_migrate_fill_args_t": _abi.MigrateFillArgs, "hmd_migrate_unpack_args_t": _abi.MigrateUnpackArgs, "hmd_pack_vote_args_t": _abi.PackVoteArgs,
+        "hmd_migrate_fill_args_t": _abi.MigrateFillArgs, "hmd_unpack_ghost_init_args_t": _abi.UnpackGhostInitArgs,
+        "hmd_vote_plan_args_t": _abi.VotePlanArgs, "hmd_migrate_unpack_args_t": _abi.MigrateUnpackArgs, "hmd_pack_vote_args_t": _abi.PackVoteArgs,
         "hmd_unpack_vote_args_t": _abi.UnpackVoteArgs, "hmd_ghost_send_list_args_t": _abi.GhostSendListArgs, "hmd_bond_table_args_t": _abi.BondTableArgs, "hmd_bond_args_t": _abi.BondArgs,
     }
     lines = ['#include "hoomd_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]

@@ -802,3 +802,79 @@ def test_migration_kernels(K, A, N, frac_out):
     assert np.array_equal(got["tag"][s], tag[li[:n_in]]) and np.array_equal(got["body"][s], body[li[:n_in]])
     assert np.array_equal(got["charge"][s], charge[li[:n_in]]) and np.array_equal(got["diameter"][s], diameter[li[:n_in]])
     assert A.lib.hmd_migrate_pack(None, None) == A.ERR_INVALID_ARGUMENT
+
+
+def test_ghost_exchange_helper_kernels(K, A):
+    """Key splitting, the first exchange's pack / unpack (tag in the upper half of w) and the row maps of the
+    exchange that carries the vote, each against the same thing written with array operations."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    # ---- keys -> index and direction arrays ----
+    n = 3000
+    idx = rng.integers(0, 2**31 - 1, n).astype(np.int64)
+    d = rng.integers(0, 26, n).astype(np.int64)
+    keys = torch.from_numpy(np.sort((d << 32) | idx)).cuda()
+    si = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sd = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    A.check(A.lib.hmd_ghost_split_keys(keys.data_ptr(), n, si.data_ptr(), sd.data_ptr(), None), "hmd_ghost_split_keys")
+    kk = keys.cpu().numpy()
+    assert np.array_equal(si.cpu().numpy(), (kk & 0xFFFFFFFF).astype(np.int32)) and np.array_equal(sd.cpu().numpy(), (kk >> 32).astype(np.uint8))
+
+    # ---- first exchange: pack with tag, unpack with defaults ----
+    N, n_send = 2000, 900
+    pos = orc.pack_pos(rng.normal(size=(N, 3)) * 5, rng.integers(0, 4, N))
+    tag = rng.permutation(N).astype(np.int32)
+    send = rng.integers(0, N, n_send).astype(np.int32)
+    sid = rng.integers(0, 27, n_send).astype(np.uint8)
+    table = rng.normal(size=(27, 3))
+    pos_t, tag_t, send_t, sid_t, table_t = (torch.from_numpy(v).cuda() for v in (pos, tag, send, sid, table))
+    out = torch.zeros((n_send, 4), dtype=torch.float64, device="cuda")
+    pa = A.PackPosArgs()
+    pa.d_out, pa.d_pos, pa.d_send_idx, pa.d_send_shift_id, pa.d_shift_table, pa.n_send = out.data_ptr(), pos_t.data_ptr(), send_t.data_ptr(), sid_t.data_ptr(), table_t.data_ptr(), n_send
+    A.check(A.lib.hmd_pack_ghost_init(C.byref(pa), tag_t.data_ptr(), None), "hmd_pack_ghost_init")
+    first, total = 50, 50 + n_send
+    g = dict(pos=torch.full((total, 4), 9.0, dtype=torch.float64, device="cuda"), image=torch.full((total, 3), 9, dtype=torch.int32, device="cuda"),
+             tag=torch.full((total,), 9, dtype=torch.int32, device="cuda"), body=torch.full((total,), 9, dtype=torch.int32, device="cuda"),
+             charge=torch.full((total,), 9.0, dtype=torch.float64, device="cuda"), diameter=torch.full((total,), 9.0, dtype=torch.float64, device="cuda"))
+    u = A.UnpackGhostInitArgs()
+    u.d_in, u.n, u.first = out.data_ptr(), n_send, first
+    u.arrays.d_pos, u.arrays.d_image, u.arrays.d_tag, u.arrays.d_body = g["pos"].data_ptr(), g["image"].data_ptr(), g["tag"].data_ptr(), g["body"].data_ptr()
+    u.arrays.d_charge, u.arrays.d_diameter = g["charge"].data_ptr(), g["diameter"].data_ptr()
+    A.check(A.lib.hmd_unpack_ghost_init(C.byref(u), None), "hmd_unpack_ghost_init")
+    exp = pos[send].copy()
+    exp[:, :3] += table[sid]
+    assert np.array_equal(g["pos"].cpu().numpy()[first:].view(np.int64), exp.view(np.int64))   # w: the type id, nothing else
+    assert np.array_equal(g["tag"].cpu().numpy()[first:], tag[send])
+    assert (g["image"][first:] == 0).all() and (g["body"][first:] == -1).all() and (g["charge"][first:] == 0).all() and (g["diameter"][first:] == 1).all()
+    assert (g["pos"][:first] == 9).all() and (g["tag"][:first] == 9).all()
+
+    # ---- row maps of the exchange with vote rows ----
+    for world, rank in ((2, 0), (2, 1), (4, 2), (8, 7), (8, 0)):
+        send_c = [int(v) for v in rng.integers(0, 40, world)]
+        recv_c = [int(v) for v in rng.integers(0, 40, world)]
+        send_c[rank] = recv_c[rank] = 0
+        if world == 4:
+            send_c[1] = recv_c[3] = 0   # an empty message still gets its vote row
+        out_row, flag_rows, in_map, off, ghost = [], [], [], 0, 0
+        for r in range(world):
+            out_row += list(range(off, off + send_c[r]))
+            if r != rank:
+                flag_rows.append(off + send_c[r])
+            off += send_c[r] + (r != rank)
+        for r in range(world):
+            in_map += list(range(ghost, ghost + recv_c[r]))
+            if r != rank:
+                in_map.append(-1)
+            ghost += recv_c[r]
+        a = A.VotePlanArgs()
+        a.n_ranks, a.rank = world, rank
+        for r in range(world + 1):
+            a.send_off[r], a.recv_off[r] = sum(send_c[:r]), sum(recv_c[:r])
+        o = torch.full((max(sum(send_c), 1),), -5, dtype=torch.int32, device="cuda")
+        f = torch.full((world - 1,), -5, dtype=torch.int32, device="cuda")
+        im = torch.full((len(in_map),), -5, dtype=torch.int32, device="cuda")
+        a.d_out_row, a.d_flag_rows, a.d_in_map = o.data_ptr(), f.data_ptr(), im.data_ptr()
+        A.check(A.lib.hmd_vote_plan(C.byref(a), None), "hmd_vote_plan")
+        assert o.cpu().tolist()[:sum(send_c)] == out_row and f.cpu().tolist() == flag_rows and im.cpu().tolist() == in_map
+    a.n_ranks = 65
+    assert A.lib.hmd_vote_plan(C.byref(a), None) == A.ERR_INVALID_ARGUMENT
