@@ -73,21 +73,16 @@ __global__ void __launch_bounds__(PFT_THREADS)
     pft_home_t* s_home = reinterpret_cast<pft_home_t*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES);
     if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
         __builtin_trap(); // the toolchain placed something before the dynamic LDS
-    if (a.d_skip_flag)
+    // One thread reads the predicate word for the whole workgroup (another stream may be raising it at this
+    // very moment: the rebuild vote of other ranks arriving; a workgroup must not split over it); the others
+    // learn it behind the barrier that follows the set-up below.
+    if (a.d_skip_flag && threadIdx.x == 0)
         {
-        // One thread reads the word for the whole workgroup: another stream may be raising it at this very
-        // moment (the rebuild vote of other ranks arriving), and a workgroup must not split over it.
-        if (threadIdx.x == 0)
-            {
-            const unsigned int word = __hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.d_published && blockIdx.x == 0)
-                __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-            s_word = word;
-            }
-        __syncthreads();
-        if (s_word == a.skip_value)
-            return;
+        const unsigned int word = __hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.d_published && blockIdx.x == 0)
+            __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        s_word = word;
         }
     const unsigned int np = a.ntypes * a.ntypes;
     // (the 12-byte home entries end on any multiple of four: the tables of doubles behind them start 16-aligned)
@@ -168,6 +163,8 @@ __global__ void __launch_bounds__(PFT_THREADS)
     if (threadIdx.x == 0)
         s_next = 2 * (PFT_THREADS / TPP);
     __syncthreads();
+    if (a.d_skip_flag && s_word == a.skip_value)
+        return;
     const unsigned int total = T.off[64];
     if (total > cap || total == 0)
         return;

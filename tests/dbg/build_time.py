@@ -36,3 +36,17 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print("tile build us", e0.elapsed_time(e1) / 10 * 1e3)
+# the same with the slot map and the slot-ordered position copy written by the build
+slot_of = torch.zeros(N, dtype=torch.int32, device="cuda")
+cpos = torch.zeros((tl["slot_meta"].shape[0], 4), dtype=torch.float64, device="cuda")
+tl["args"].d_slot_of = slot_of.data_ptr()
+tl["args"].geom.d_cpos = cpos.data_ptr()
+for _ in range(2):
+    A.check(A.lib.hmd_compute_nlist_tiles(C.byref(tl["args"]), None))
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    A.check(A.lib.hmd_compute_nlist_tiles(C.byref(tl["args"]), None))
+e1.record()
+torch.cuda.synchronize()
+print("tile build with slot map + positions us", e0.elapsed_time(e1) / 10 * 1e3)
