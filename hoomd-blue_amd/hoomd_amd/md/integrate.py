@@ -1,5 +1,6 @@
 """The MD integrator (hoomd/md/integrate.py:141-326)."""
 from .. import _hoomd_amd as _cpp
+from ..operation import AutotunedObject
 
 
 class _SyncedList(list):
@@ -37,7 +38,7 @@ class _SyncedList(list):
         self._changed()
 
 
-class Integrator:
+class Integrator(AutotunedObject):
     """``Integrator(dt, methods=[...], forces=[...])``; constraints, rigid bodies, rotational degrees
     of freedom and half-step hooks of the reference are outside this backend's scope and rejected."""
 

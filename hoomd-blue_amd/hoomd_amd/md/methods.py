@@ -1,6 +1,7 @@
 """Integration methods (hoomd/md/methods/methods.py, hoomd/md/methods/thermostats.py)."""
 from .. import _hoomd_amd as _cpp
 from .. import filter as _filter
+from ..operation import AutotunedObject
 
 
 class Thermostat:
@@ -45,8 +46,11 @@ class thermostats:  # namespace mirror of hoomd.md.methods.thermostats
     Thermostat = Thermostat
 
 
-class Method:
+class Method(AutotunedObject):
     _cpp_obj = None
+
+    def _kernel_parameters(self):
+        return {"step_one": (256,), "step_two": (256,)}
 
 
 class ConstantVolume(Method):

@@ -3,9 +3,10 @@ import numpy as np
 
 from .. import _hoomd_amd as _cpp
 from ..error import DataAccessError
+from ..operation import AutotunedObject
 
 
-class NeighborList:
+class NeighborList(AutotunedObject):
     """Base class (hoomd/md/nlist.py:84-323)."""
 
     def __init__(self, buffer, exclusions, rebuild_check_delay, check_dist, mesh):
@@ -60,6 +61,10 @@ class NeighborList:
         """Exclude one pair by tag (NeighborList::addExclusion, hoomd/md/NeighborList.cc:569)."""
         self._require_attached("add_exclusion")
         self._cpp_obj.addExclusion(int(tag_i), int(tag_j))
+
+    def _kernel_parameters(self):
+        # block sizes of the cell-list, neighbor-list and distance-check kernels (fixed for gfx950)
+        return {"cell_list": (256,), "nlist_binned": (256,), "nlist_needs_update": (256,)}
 
     def _require_attached(self, name):
         if self._cpp_obj is None:

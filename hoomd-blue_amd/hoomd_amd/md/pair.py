@@ -4,6 +4,7 @@ import numpy as np
 from .. import _hoomd_amd as _cpp
 from ..error import DataAccessError, MutabilityError
 from ..typeparam import PairTypeParameter
+from ..operation import AutotunedObject
 from .nlist import NeighborList
 
 _MODES = {"none": 0, "shift": 1, "xplor": 2}
@@ -16,7 +17,7 @@ def _pos_float(v):
     return v
 
 
-class Force:
+class Force(AutotunedObject):
     """Per-particle results of a force compute (hoomd/md/force.py:60-215)."""
 
     _cpp_obj = None
@@ -111,6 +112,15 @@ class Pair(Force):
         self._mode = value
         if self._cpp_obj is not None:
             self._cpp_obj.mode = _MODES[value]
+
+    def _kernel_parameters(self):
+        # (block size, lanes per particle); 0 lanes = the library's choice for the list at hand
+        return {"pair_force": (256, int(self._cpp_obj.threads_per_particle))}
+
+    def _set_kernel_parameter(self, name, values):
+        if len(values) != 2 or values[0] != 256 or values[1] not in (0, 1, 2, 4, 8, 16, 32, 64):
+            raise ValueError("pair_force takes (256, lanes per particle) with lanes a power of two up to 64, or 0")
+        self._cpp_obj.threads_per_particle = values[1]
 
     def _attach(self, sim):
         """hoomd/md/pair/pair.py:126-144: attach the neighbor list, force the full storage mode the

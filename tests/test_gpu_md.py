@@ -371,3 +371,32 @@ def test_example_plugin_force_and_energy(hoomd, distance, k, mode):
         np.testing.assert_array_almost_equal(ex.forces, [-f, f], decimal=6)
         np.testing.assert_array_almost_equal(ex.energies, [e / 2, e / 2], decimal=6)
         assert ex.params[("A", "A")] == dict(k=k, sigma=sigma)
+
+
+def test_autotuner_interface_answers(hoomd):
+    """hoomd/operation.py:386-476: kernel_parameters / is_tuning_complete / tune_kernel_parameters exist on every
+    operation; before attaching they raise as the reference does."""
+    snap = jittered_lattice_snapshot(hoomd, 10, jitter=0.05)
+    sim, cell, lj, method = make_sim(hoomd, snap)
+    with pytest.raises(hoomd.error.DataAccessError):
+        lj.kernel_parameters
+    with pytest.raises(RuntimeError):
+        cell.tune_kernel_parameters()
+    sim.run(0)
+    F0 = lj.forces
+    for op in (cell, lj, method, sim.operations.integrator):
+        assert op.is_tuning_complete is True
+        assert isinstance(op.kernel_parameters, dict)
+        op.tune_kernel_parameters()
+        op.kernel_parameters = op.kernel_parameters   # saving and restoring the tuned values round-trips
+    assert lj.kernel_parameters["pair_force"] == (256, 0)
+    lj.kernel_parameters = {"pair_force": (256, 16)}
+    assert lj.kernel_parameters["pair_force"] == (256, 16) and lj._cpp_obj.threads_per_particle == 16
+    sim.run(1)
+    sim2, cell2, lj2, _ = make_sim(hoomd, snap)
+    sim2.run(1)
+    assert np.abs(lj.forces - lj2.forces).max() < 1e-9 * max(1.0, np.abs(F0).max())
+    with pytest.raises(ValueError):
+        lj.kernel_parameters = {"pair_force": (128, 8)}
+    with pytest.raises(ValueError):
+        cell.kernel_parameters = {"no_such_kernel": (1,)}
