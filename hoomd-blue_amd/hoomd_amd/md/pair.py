@@ -113,6 +113,15 @@ class Pair(Force):
         if self._cpp_obj is not None:
             self._cpp_obj.mode = _MODES[value]
 
+    def compute_energy(self, tags1, tags2):
+        """U = sum over i in tags1, j in tags2 of V_ij(r) (hoomd/md/pair/pair.py:90-124); the sets are assumed
+        disjoint and free of duplicates, as in the reference."""
+        if self._cpp_obj is None:
+            raise DataAccessError("compute_energy")
+        t1 = [int(t) for t in np.asarray(tags1).ravel()]
+        t2 = [int(t) for t in np.asarray(tags2).ravel()]
+        return float(self._cpp_obj.computeEnergyBetweenSets(t1, t2))
+
     def _kernel_parameters(self):
         # (block size, lanes per particle); 0 lanes = the library's choice for the list at hand
         return {"pair_force": (256, int(self._cpp_obj.threads_per_particle))}

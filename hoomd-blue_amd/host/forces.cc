@@ -276,6 +276,73 @@ bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigne
     return a.N != 0; // the drivers launch nothing for an empty system
     }
 
+// hoomd/md/PotentialPair.h:833-991
+template<class Ev> Scalar PotentialPairGPU<Ev>::computeEnergyBetweenSets(const std::vector<unsigned int>& tags1, const std::vector<unsigned int>& tags2)
+    {
+    if (tags1.empty() || tags2.empty())
+        return 0;
+    if (m_sysdef->isDomainDecomposed())
+        throw std::runtime_error("computeEnergyBetweenSets is not available under domain decomposition");
+    const unsigned int N = m_pdata->getN(), n_tags = m_pdata->getNGlobal();
+    std::vector<Scalar4> pos(N);
+    std::vector<unsigned int> rtag(n_tags);
+    hipCheck(hipMemcpy(pos.data(), m_pdata->pos(), sizeof(Scalar4) * N, hipMemcpyDeviceToHost), "pos D2H");
+    hipCheck(hipMemcpy(rtag.data(), m_pdata->rtag(), sizeof(unsigned int) * n_tags, hipMemcpyDeviceToHost), "rtag D2H");
+    const hmd_box_t b = m_pdata->getGlobalBox().b;
+    Scalar energy = 0;
+    for (unsigned int t1 : tags1)
+        {
+        if (t1 >= n_tags)
+            throw std::invalid_argument("computeEnergyBetweenSets: tag out of range");
+        const unsigned int i = rtag[t1];
+        if (i >= N)
+            continue;
+        unsigned int typei;
+        std::memcpy(&typei, &pos[i].w, sizeof(unsigned int));
+        for (unsigned int t2 : tags2)
+            {
+            if (t2 >= n_tags)
+                throw std::invalid_argument("computeEnergyBetweenSets: tag out of range");
+            const unsigned int j = rtag[t2];
+            if (j >= N)
+                continue;
+            Scalar dx = pos[i].x - pos[j].x, dy = pos[i].y - pos[j].y, dz = pos[i].z - pos[j].z;
+            // minimum image (hoomd/BoxDim.h:301-375)
+            if (b.periodic[2])
+                {
+                const Scalar img = std::rint(dz * b.Linv[2]);
+                dz -= b.L[2] * img;
+                dy -= b.L[2] * b.yz * img;
+                dx -= b.L[2] * b.xz * img;
+                }
+            if (b.periodic[1])
+                {
+                const Scalar img = std::rint(dy * b.Linv[1]);
+                dy -= b.L[1] * img;
+                dx -= b.L[1] * b.xy * img;
+                }
+            if (b.periodic[0])
+                dx -= b.L[0] * std::rint(dx * b.Linv[0]);
+            const Scalar rsq = dx * dx + dy * dy + dz * dz;
+            unsigned int typej;
+            std::memcpy(&typej, &pos[j].w, sizeof(unsigned int));
+            const size_t tp = (size_t)typej * m_ntypes + typei;
+            const Scalar rcutsq = m_rcutsq[tp], ronsq = m_shift_mode == xplor ? m_ronsq[tp] : 0.0;
+            const bool energy_shift = m_shift_mode == shift || (m_shift_mode == xplor && ronsq > rcutsq);
+            Scalar pair_eng = 0;
+            if (!Ev::evalEnergy(rsq, rcutsq, m_params[tp], energy_shift, pair_eng))
+                continue;
+            if (m_shift_mode == xplor && rsq >= ronsq && rsq < rcutsq)
+                {
+                const Scalar d = rcutsq - ronsq, m = rsq - rcutsq;
+                pair_eng *= m * m * (rcutsq + 2.0 * rsq - 3.0 * ronsq) / (d * d * d);
+                }
+            energy += pair_eng;
+            }
+        }
+    return energy;
+    }
+
 // hoomd/md/PotentialPair.h:255-341 (single rank: the per-type counts come from the type ids)
 template<class Ev> void PotentialPairGPU<Ev>::computeTailCorrection()
     {

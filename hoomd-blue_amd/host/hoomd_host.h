@@ -14,6 +14,7 @@
 
 #include <array>
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -1182,6 +1183,21 @@ struct EvaluatorLJHost
     //! hoomd/md/EvaluatorPairLJ.h:213-248
     static Scalar energyLRC(Scalar rcutsq, const param_type& p);
     static Scalar pressureLRC(Scalar rcutsq, const param_type& p);
+    //! pair energy on the host (hoomd/md/EvaluatorPairLJ.h:165-207), for computeEnergyBetweenSets
+    static bool evalEnergy(Scalar rsq, Scalar rcutsq, const param_type& p, bool energy_shift, Scalar& pair_eng)
+        {
+        const Scalar lj1 = p.epsilon_x_4 * p.sigma_6 * p.sigma_6, lj2 = p.epsilon_x_4 * p.sigma_6;
+        if (!(rsq < rcutsq) || lj1 == 0)
+            return false;
+        const Scalar r2inv = 1.0 / rsq, r6inv = r2inv * r2inv * r2inv;
+        pair_eng = r6inv * (lj1 * r6inv - lj2);
+        if (energy_shift)
+            {
+            const Scalar rcut2inv = 1.0 / rcutsq, rcut6inv = rcut2inv * rcut2inv * rcut2inv;
+            pair_eng -= rcut6inv * (lj1 * rcut6inv - lj2);
+            }
+        return true;
+        }
     };
 
 struct EvaluatorExampleHost
@@ -1206,6 +1222,20 @@ struct EvaluatorExampleHost
     static Scalar pressureLRC(Scalar, const param_type&)
         {
         return 0;
+        }
+    //! example_plugins/pair_plugin/EvaluatorPairExample.h:83-133
+    static bool evalEnergy(Scalar rsq, Scalar rcutsq, const param_type& p, bool energy_shift, Scalar& pair_eng)
+        {
+        if (!(rsq < rcutsq))
+            return false;
+        const Scalar overlap = p.sigma - std::sqrt(rsq);
+        pair_eng = 0.5 * p.k * overlap * overlap;
+        if (energy_shift)
+            {
+            const Scalar co = p.sigma - std::sqrt(rcutsq);
+            pair_eng -= 0.5 * p.k * co * co;
+            }
+        return true;
         }
     };
 
@@ -1261,6 +1291,9 @@ template<class Ev> class PotentialPairGPU : public ForceCompute
         {
         return m_nlist;
         }
+    //! U = sum over i in tags1, j in tags2 of V_ij (hoomd/md/PotentialPair.h:833-991): a host-side double loop
+    //! over the two sets with the minimum image in the global box, as in the reference
+    Scalar computeEnergyBetweenSets(const std::vector<unsigned int>& tags1, const std::vector<unsigned int>& tags2);
 
     protected:
     void computeForces(uint64_t timestep) override;

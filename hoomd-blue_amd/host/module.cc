@@ -143,6 +143,7 @@ template<class Ev, class P2D, class D2P> void export_pair(py::module& m, const c
         .def_property("mode", [](T& self) { return (int)self.getShiftMode(); },
                       [](T& self, int mode) { self.setShiftMode((typename T::energyShiftMode)mode); })
         .def_property("tail_correction", &T::getTailCorrectionEnabled, &T::setTailCorrectionEnabled)
+        .def("computeEnergyBetweenSets", &T::computeEnergyBetweenSets)
         .def_property("threads_per_particle", &T::getThreadsPerParticle, &T::setThreadsPerParticle);
     }
     } // namespace

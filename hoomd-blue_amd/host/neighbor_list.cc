@@ -57,10 +57,10 @@ NeighborListGPUBinned::~NeighborListGPUBinned()
     m_pdata->getMaxParticleNumberChangeSignal().disconnect(m_maxn_slot);
     if (m_comm_stream)
         {
-        hipStreamSynchronize(m_comm_stream);
-        hipStreamDestroy(m_comm_stream);
-        hipEventDestroy(m_ev_ready);
-        hipEventDestroy(m_ev_comm);
+        (void)hipStreamSynchronize(m_comm_stream);
+        (void)hipStreamDestroy(m_comm_stream);
+        (void)hipEventDestroy(m_ev_ready);
+        (void)hipEventDestroy(m_ev_comm);
         }
     }
 

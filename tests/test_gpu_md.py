@@ -400,3 +400,46 @@ def test_autotuner_interface_answers(hoomd):
         lj.kernel_parameters = {"pair_force": (128, 8)}
     with pytest.raises(ValueError):
         cell.kernel_parameters = {"no_such_kernel": (1,)}
+
+
+@pytest.mark.parametrize("mode", ["none", "shift", "xplor"])
+def test_compute_energy_between_sets(hoomd, mode):
+    """hoomd/md/pair/pair.py:90-124: even against odd tags; the two halves of the total energy by set."""
+    snap = jittered_lattice_snapshot(hoomd, 8, jitter=0.08, seed=4)
+    N = snap.particles.N
+    sim, cell, lj, _ = make_sim(hoomd, snap, mode=mode)
+    if mode == "xplor":
+        lj.r_on[("A", "A")] = 2.0
+    with pytest.raises(hoomd.error.DataAccessError):
+        lj.compute_energy([0], [1])
+    sim.run(0)
+    tags = np.arange(N, dtype=np.int32)
+    even, odd = tags[0::2], tags[1::2]
+    u_eo = lj.compute_energy(even, odd)
+    # brute force over all even-odd pairs: minimum image, LJ with the mode's energy modification
+    # (hoomd/md/PotentialPair.h:912-976, hoomd/md/EvaluatorPairLJ.h:165-207)
+    pos, _, L = oracle_inputs(snap)
+
+    def pair_energy(ti, tj):
+        d = pos[ti, None, :3] - pos[None, tj, :3]
+        d -= np.rint(d / L) * L
+        rsq = (d * d).sum(-1)
+        r6 = 1.0 / rsq**3
+        e = 4.0 * (r6 * r6 - r6)
+        rc2, ron2 = 6.25, 4.0
+        if mode == "shift":
+            e -= 4.0 * (1.0 / rc2**6 - 1.0 / rc2**3)
+        if mode == "xplor":
+            sw = (rsq - rc2) ** 2 * (rc2 + 2 * rsq - 3 * ron2) / (rc2 - ron2) ** 3
+            e = np.where(rsq >= ron2, e * sw, e)
+        return np.where(rsq < rc2, e, 0.0)
+
+    want = pair_energy(even, odd).sum()
+    assert np.isclose(u_eo, want, rtol=1e-11)
+    assert np.isclose(lj.compute_energy(odd, even), u_eo, rtol=1e-12)
+    assert lj.compute_energy([], odd) == 0.0
+    # one particle against everybody else = twice its per-particle energy
+    i = 17
+    others = np.delete(tags, i)
+    assert np.isclose(lj.compute_energy([i], others), 2 * lj.energies[i], rtol=1e-10)
+    assert np.isclose(lj.compute_energy([i], others), pair_energy(np.array([i]), others).sum(), rtol=1e-11)
