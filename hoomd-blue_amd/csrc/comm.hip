@@ -150,9 +150,30 @@ __device__ __forceinline__ long long bits_of(double v)
 __global__ void __launch_bounds__(256) migrate_pack_kernel(hmd_migrate_pack_args_t a)
     {
     const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.slot_rows && k < a.n_ranks)
+        {
+        // header of the message to rank k
+        unsigned int most = 0;
+        for (unsigned int r = 0; r < a.n_ranks; r++)
+            most = max(most, a.send_off[r + 1] - a.send_off[r]);
+        long long* h = a.d_out + (size_t)k * (a.slot_rows + 1) * HMD_MIGRATE_ROW_WORDS;
+        h[0] = (long long)(a.send_off[k + 1] - a.send_off[k]);
+        h[1] = (long long)most;
+        h[2] = (long long)a.slot_rows;
+        }
     if (k >= a.n)
         return;
-    const unsigned int i = (unsigned int)(a.d_keys[k] & 0xffffffffull);
+    const unsigned long long key = a.d_keys[k];
+    const unsigned int i = (unsigned int)(key & 0xffffffffull);
+    size_t out_row = k;
+    if (a.slot_rows)
+        {
+        const unsigned int dest = (unsigned int)(key >> 32);
+        const unsigned int local = k - a.send_off[dest];
+        if (dest >= a.n_ranks || local >= a.slot_rows)
+            return; // does not fit this round's messages
+        out_row = (size_t)dest * (a.slot_rows + 1) + 1 + local;
+        }
     const double4 p = hmd_ld4(a.arrays.d_pos + i);
     const double4 v = hmd_ld4(a.arrays.d_vel + i);
     const hmd_scalar3 acc = a.arrays.d_accel[i];
@@ -168,7 +189,7 @@ __global__ void __launch_bounds__(256) migrate_pack_kernel(hmd_migrate_pack_args
         x[d] = HMD_SUB(x[d], HMD_MUL(w, a.global_L[d]));
         im[d] += (long long)w;
         }
-    long long* row = a.d_out + (size_t)k * HMD_MIGRATE_ROW_WORDS;
+    long long* row = a.d_out + out_row * HMD_MIGRATE_ROW_WORDS;
     row[0] = bits_of(x[0]);
     row[1] = bits_of(x[1]);
     row[2] = bits_of(x[2]);
@@ -194,7 +215,15 @@ __global__ void __launch_bounds__(256) migrate_unpack_kernel(hmd_migrate_unpack_
     const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n)
         return;
-    const long long* row = a.d_in + (size_t)k * HMD_MIGRATE_ROW_WORDS;
+    size_t in_row = k;
+    if (a.slot_rows)
+        {
+        unsigned int r = 0;
+        while (a.recv_off[r + 1] <= k)
+            r++;
+        in_row = (size_t)r * (a.slot_rows + 1) + 1 + (k - a.recv_off[r]);
+        }
+    const long long* row = a.d_in + in_row * HMD_MIGRATE_ROW_WORDS;
     const unsigned int i = a.first + k;
     hmd_st4(a.arrays.d_pos + i, __longlong_as_double(row[0]), __longlong_as_double(row[1]), __longlong_as_double(row[2]), __longlong_as_double(row[3]));
     hmd_st4(a.arrays.d_vel + i, __longlong_as_double(row[4]), __longlong_as_double(row[5]), __longlong_as_double(row[6]), __longlong_as_double(row[7]));
@@ -475,13 +504,23 @@ static bool pdata_arrays_complete(const hmd_pdata_arrays_t& p)
 extern "C" int hmd_migrate_pack(const hmd_migrate_pack_args_t* args, void* stream)
     {
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack: args is NULL");
-    if (args->n == 0)
+    if (args->slot_rows)
+        {
+        HMD_REQUIRE(args->n_ranks >= 1 && args->n_ranks <= 64 && args->d_out, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_migrate_pack: fixed-size messages need 1 to 64 ranks and d_out");
+        HMD_REQUIRE(args->send_off[0] == 0 && args->send_off[args->n_ranks] == args->n, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_migrate_pack: send_off must start at 0 and end at n");
+        for (unsigned int r = 0; r < args->n_ranks; r++)
+            HMD_REQUIRE(args->send_off[r] <= args->send_off[r + 1], HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack: send_off must not decrease");
+        }
+    else if (args->n == 0)
         return HMD_OK;
-    HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_keys && args->d_out, HMD_ERR_INVALID_ARGUMENT,
+    HMD_REQUIRE(args->n == 0 || (pdata_arrays_complete(args->arrays) && args->d_keys && args->d_out), HMD_ERR_INVALID_ARGUMENT,
                 "hmd_migrate_pack: all particle arrays, d_keys and d_out are required");
     for (int d = 0; d < 3; d++)
         HMD_REQUIRE(args->global_L[d] > 0.0, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack: empty box");
-    hipLaunchKernelGGL(migrate_pack_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+    const unsigned int threads = args->slot_rows ? std::max(args->n, args->n_ranks) : args->n;
+    hipLaunchKernelGGL(migrate_pack_kernel, dim3(hmd_div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }
 
@@ -503,6 +542,15 @@ extern "C" int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* s
     if (args->n == 0)
         return HMD_OK;
     HMD_REQUIRE(pdata_arrays_complete(args->arrays) && args->d_in, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_unpack: all particle arrays and d_in are required");
+    if (args->slot_rows)
+        {
+        HMD_REQUIRE(args->n_ranks >= 1 && args->n_ranks <= 64, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_unpack: fixed-size messages need 1 to 64 ranks");
+        HMD_REQUIRE(args->recv_off[0] == 0 && args->recv_off[args->n_ranks] == args->n, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_migrate_unpack: recv_off must start at 0 and end at n");
+        for (unsigned int r = 0; r < args->n_ranks; r++)
+            HMD_REQUIRE(args->recv_off[r] <= args->recv_off[r + 1] && args->recv_off[r + 1] - args->recv_off[r] <= args->slot_rows, HMD_ERR_INVALID_ARGUMENT,
+                        "hmd_migrate_unpack: recv_off must not decrease, and no message holds more than slot_rows particles");
+        }
     hipLaunchKernelGGL(migrate_unpack_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }

@@ -175,7 +175,8 @@ MIGRATE_ROW_WORDS = 18
 
 class MigratePackArgs(C.Structure):
     _fields_ = [("arrays", PDataArraysStruct), ("d_keys", vp), ("n", u32), ("global_lo", f64 * 3), ("global_L", f64 * 3),
-                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("d_out", vp)]
+                ("decomposed", C.c_ubyte * 3), ("pad_", C.c_ubyte), ("d_out", vp), ("slot_rows", u32), ("n_ranks", u32),
+                ("send_off", u32 * 65)]
 
 
 class MigrateFillArgs(C.Structure):
@@ -196,7 +197,8 @@ class VotePlanArgs(C.Structure):
 
 
 class MigrateUnpackArgs(C.Structure):
-    _fields_ = [("arrays", PDataArraysStruct), ("d_in", vp), ("first", u32), ("n", u32)]
+    _fields_ = [("arrays", PDataArraysStruct), ("d_in", vp), ("first", u32), ("n", u32), ("slot_rows", u32), ("n_ranks", u32),
+                ("recv_off", u32 * 65)]
 
 
 class GhostSendListArgs(C.Structure):

@@ -317,6 +317,12 @@ class ParticleExchange:
         self.n_migrated_in = 0
         self._vote = None
         self._mig_dest = None
+        self._mig_fixed = None
+        self._mig_slot_rows = int(os.environ.get("HOOMD_AMD_MIGRATE_SLOT_ROWS", "1024"))
+        # fixed-size migration messages: when every other rank is a neighbor of this one
+        peers = [r for r in range(dd.world) if r != dd.rank]
+        self._fixed_migrate = (self.device.type == "cuda" and 2 <= dd.world <= 64 and sorted(set(self.dir_dest)) == peers
+                               and os.environ.get("HOOMD_AMD_FIXED_MIGRATE", "1") != "0")
         self._mig_counters = None
         self._mig_keys = None
         self._mig_empty = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
@@ -390,22 +396,53 @@ class ParticleExchange:
             self._mig_keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
         n_leave, send_counts = counters[0], counters[1:]
         keys = None
-        payload = self._mig_empty
         if n_leave:
             keys, _ = torch.sort(self._mig_keys[:n_leave])
-            payload = torch.empty((n_leave, _ELEM), dtype=torch.int64, device=self.device)
-            pk = m.MigratePackArgs()
-            pk.arrays, pk.d_keys, pk.n, pk.d_out = self._pdata_struct(), keys.data_ptr(), n_leave, payload.data_ptr()
-            pk.global_lo[:], pk.global_L[:] = list(dd.glo), list(dd.gL)
-            pk.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
-            m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
-        recv_counts = self._exchange_counts(send_counts)
-        n_recv = sum(recv_counts)
+        pk = m.MigratePackArgs()
+        pk.arrays, pk.d_keys, pk.n = self._pdata_struct(), (keys.data_ptr() if n_leave else None), n_leave
+        pk.global_lo[:], pk.global_L[:] = list(dd.glo), list(dd.gL)
+        pk.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
+        slot_rows = 0
+        if self._fixed_migrate:
+            # Every rank exchanges with every other rank: messages of a fixed number of rows, each headed by its
+            # particle count and the sender's largest count.  All ranks see all headers, so all of them know
+            # every message size, and whether any message was too small, without an exchange of counts.
+            off = 0
+            for r in range(world):
+                pk.send_off[r] = off
+                off += send_counts[r]
+            pk.send_off[world] = off
+            pk.n_ranks = world
+            while True:
+                slot_rows = self._mig_slot_rows
+                rows = world * (slot_rows + 1)
+                if self._mig_fixed is None or self._mig_fixed[0].shape[0] < rows:
+                    self._mig_fixed = (torch.zeros((rows, _ELEM), dtype=torch.int64, device=self.device),
+                                       torch.zeros((rows, _ELEM), dtype=torch.int64, device=self.device))
+                payload, incoming = self._mig_fixed[0][:rows], self._mig_fixed[1][:rows]
+                pk.slot_rows, pk.d_out = slot_rows, payload.data_ptr()
+                m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
+                self._a2a(incoming, payload, None, None)
+                headers = incoming.view(world, slot_rows + 1, _ELEM)[:, 0, :2].tolist()
+                most = max(h[1] for h in headers)
+                if most <= slot_rows:
+                    break
+                self._mig_slot_rows = 2 * int(most)  # the same decision on every rank: send again with room for all
+            recv_counts = [int(h[0]) for h in headers]
+            n_recv = sum(recv_counts)
+        else:
+            payload = self._mig_empty
+            if n_leave:
+                payload = torch.empty((n_leave, _ELEM), dtype=torch.int64, device=self.device)
+                pk.d_out = payload.data_ptr()
+                m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
+            recv_counts = self._exchange_counts(send_counts)
+            n_recv = sum(recv_counts)
+            # every rank takes part in the collective, also with nothing to send or receive
+            incoming = torch.empty((n_recv, _ELEM), dtype=torch.int64, device=self.device) if n_recv else self._mig_empty_in
+            self._a2a(incoming, payload, recv_counts, send_counts)
         self.n_migrated_out += n_leave
         self.n_migrated_in += n_recv
-        # every rank takes part in the collective, also with nothing to send or receive
-        incoming = torch.empty((n_recv, _ELEM), dtype=torch.int64, device=self.device) if n_recv else self._mig_empty_in
-        self._a2a(incoming, payload, recv_counts, send_counts)
         if n_leave == 0 and n_recv == 0:
             return False
         n_keep = N - n_leave
@@ -419,6 +456,13 @@ class ParticleExchange:
         if n_recv:
             u = m.MigrateUnpackArgs()
             u.arrays, u.d_in, u.first, u.n = self._pdata_struct(), incoming.data_ptr(), n_keep, n_recv
+            if slot_rows:
+                u.slot_rows, u.n_ranks = slot_rows, world
+                off = 0
+                for r in range(world):
+                    u.recv_off[r] = off
+                    off += recv_counts[r]
+                u.recv_off[world] = off
             m.check(m.lib.hmd_migrate_unpack(ctypes.byref(u), None), "hmd_migrate_unpack")
         return True
 

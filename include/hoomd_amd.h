@@ -713,6 +713,15 @@ typedef struct
     unsigned char decomposed[3];
     unsigned char pad_;
     long long* d_out;
+    /* Optional fixed-size messages (slot_rows > 0, n_ranks <= 64): the message to rank r occupies rows
+       [r * (slot_rows + 1), (r + 1) * (slot_rows + 1)) of d_out; its first row is a header (word 0: number of
+       particles for r, word 1: the largest such number over all r, word 2: slot_rows), the particles follow;
+       those beyond slot_rows are dropped (the receiver sees it in the header).  send_off: exclusive prefix sums of
+       the keys per destination rank (n_ranks + 1 entries).  Receivers then know every message size without a
+       separate exchange of counts.  With slot_rows == 0 rows are written back to back in key order. */
+    unsigned int slot_rows;
+    unsigned int n_ranks;
+    unsigned int send_off[65];
     } hmd_migrate_pack_args_t;
 int hmd_migrate_pack(const hmd_migrate_pack_args_t* args, void* stream);
 
@@ -741,6 +750,11 @@ typedef struct
     const long long* d_in;
     unsigned int first;
     unsigned int n;
+    /* Optional, the receiving side of fixed-size messages: row k of the particles comes from the message of the
+       rank r with recv_off[r] <= k < recv_off[r + 1], at row r * (slot_rows + 1) + 1 + (k - recv_off[r]) of d_in. */
+    unsigned int slot_rows;
+    unsigned int n_ranks;
+    unsigned int recv_off[65];
     } hmd_migrate_unpack_args_t;
 int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* stream);
 

@@ -75,7 +75,8 @@ def main():
                  overlapped=int(cell._cpp_obj.num_overlapped))
     if dd is not None:
         ex = dd.communicator.exchange
-        stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges))
+        stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges),
+                     fixed_migrate=int(ex._fixed_migrate), slot_rows=int(ex._mig_slot_rows))
         allstats = [None] * world
         dist.all_gather_object(allstats, stats)
     else:
@@ -84,7 +85,8 @@ def main():
         np.savez(out, position=s.particles.position, velocity=s.particles.velocity, image=s.particles.image, e0=e0, e1=e1,
                  dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
                  builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats],
-                 vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats], overlapped=[a["overlapped"] for a in allstats])
+                 vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats], overlapped=[a["overlapped"] for a in allstats],
+                 fixed_migrate=[a.get("fixed_migrate", 0) for a in allstats], slot_rows=[a.get("slot_rows", 0) for a in allstats])
     if dd is not None:
         dist.barrier()
         dist.destroy_process_group()

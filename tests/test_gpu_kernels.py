@@ -771,6 +771,41 @@ def test_migration_kernels(K, A, N, frac_out):
                           diameter[li].view(np.int64)[:, None]], axis=1)
     assert np.array_equal(payload.cpu().numpy()[:n_leave], exp)
 
+    # ---- the same rows as fixed-size messages with headers; a slot that is too small drops the excess ----
+    counts = np.bincount(want_dest[leave], minlength=world)
+    for K in (int(counts.max()) + 3, max(int(counts.max()) // 2, 1)):
+        fixed = torch.full((world * (K + 1), A.MIGRATE_ROW_WORDS), -7, dtype=torch.int64, device="cuda")
+        pk.slot_rows, pk.n_ranks, pk.d_out = K, world, fixed.data_ptr()
+        for r in range(world + 1):
+            pk.send_off[r] = int(counts[:r].sum())
+        A.check(A.lib.hmd_migrate_pack(C.byref(pk), None), "hmd_migrate_pack")
+        fx = fixed.cpu().numpy().reshape(world, K + 1, -1)
+        for r in range(world):
+            assert fx[r, 0, 0] == counts[r] and fx[r, 0, 1] == counts.max() and fx[r, 0, 2] == K
+            take = min(int(counts[r]), K)
+            first = int(counts[:r].sum())
+            assert np.array_equal(fx[r, 1:1 + take], exp[first:first + take])
+            assert (fx[r, 1 + take:] == -7).all()
+    pk.slot_rows, pk.d_out = 0, payload.data_ptr()
+    if n_leave and n_leave <= extra:
+        # unpack from the roomy fixed-size layout = unpack from the back-to-back rows
+        K = int(counts.max()) + 3
+        fixed = torch.zeros((world * (K + 1), A.MIGRATE_ROW_WORDS), dtype=torch.int64, device="cuda")
+        pk.slot_rows, pk.d_out = K, fixed.data_ptr()
+        A.check(A.lib.hmd_migrate_pack(C.byref(pk), None), "hmd_migrate_pack")
+        pk.slot_rows, pk.d_out = 0, payload.data_ptr()
+        probe = {k: torch.zeros_like(v) for k, v in dev.items()}
+        uf = A.MigrateUnpackArgs()
+        uf.arrays.d_pos, uf.arrays.d_vel, uf.arrays.d_accel, uf.arrays.d_image = probe["pos"].data_ptr(), probe["vel"].data_ptr(), probe["accel"].data_ptr(), probe["image"].data_ptr()
+        uf.arrays.d_tag, uf.arrays.d_body, uf.arrays.d_charge, uf.arrays.d_diameter = probe["tag"].data_ptr(), probe["body"].data_ptr(), probe["charge"].data_ptr(), probe["diameter"].data_ptr()
+        uf.d_in, uf.first, uf.n, uf.slot_rows, uf.n_ranks = fixed.data_ptr(), 5, n_leave, K, world
+        for r in range(world + 1):
+            uf.recv_off[r] = int(counts[:r].sum())
+        A.check(A.lib.hmd_migrate_unpack(C.byref(uf), None), "hmd_migrate_unpack")
+        assert np.array_equal(probe["tag"].cpu().numpy()[5:5 + n_leave], tag[li])
+        assert np.array_equal(probe["pos"].cpu().numpy()[5:5 + n_leave].view(np.int64), exp[:, 0:4])
+        assert np.array_equal(probe["diameter"].cpu().numpy()[5:5 + n_leave], diameter[li])
+
     # ---- fill the gaps: the stayers, each with all of its fields, end up in [0, n_keep) ----
     n_keep = N - n_leave
     scratch = torch.zeros(max(2 * n_leave, 1), dtype=torch.int32, device="cuda")
