@@ -17,7 +17,7 @@ from test_comm_gloo import launch  # noqa: E402
     (2, (1, 1, 2), 0, (16, 16, 16), False), (4, (2, 2, 1), 1, (16, 16, 16), False), (8, (2, 2, 2), 1, (20, 20, 20), False),
     # sub-boxes long enough along the decomposed axes to have tile blocks that see no ghosts: their forces are
     # computed on a second stream while the halo exchange runs
-    (2, (1, 1, 2), 1, (10, 10, 36), True), (4, (2, 2, 1), 0, (36, 36, 10), True)])
+    (2, (1, 1, 2), 1, (10, 10, 36), True), (4, (2, 2, 1), 0, (36, 36, 10), True), (8, (2, 2, 2), 1, (36, 36, 36), True)])
 def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, overlap):
     steps = 60
     ref = str(tmp_path / "ref.npz")
