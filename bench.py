@@ -97,6 +97,11 @@ def main():
         N, steps, dt, builds, n = cpu_baseline_replica()
         print(json.dumps({"N": N, "steps": steps, "seconds": dt, "builds": int(builds), "n": list(n)}), flush=True)
         return
+    # Libraries print banners on the C-level standard output (RCCL does at start-up): everything written to
+    # file descriptor 1 goes to standard error until the result line, which is then the only line on stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
@@ -278,7 +283,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if world > 1 or args.force_dd:
         dist.barrier()
