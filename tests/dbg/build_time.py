@@ -50,3 +50,11 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print("tile build with slot map + positions us", e0.elapsed_time(e1) / 10 * 1e3)
+# launch by launch: on some boxes of the pool the duration alternates between two values
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+ev[0].record()
+for i in range(40):
+    A.check(A.lib.hmd_compute_nlist_tiles(C.byref(tl["args"]), None))
+    ev[i + 1].record()
+torch.cuda.synchronize()
+print("per launch us", [round(ev[i].elapsed_time(ev[i + 1]) * 1e3) for i in range(40)])
