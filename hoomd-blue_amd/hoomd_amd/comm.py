@@ -336,6 +336,7 @@ class ParticleExchange:
         self._keys = None
         self._send_counters = None
         self._send_buf = None
+        self._pdata_cache = None
         self._init_buf = None
         self._plan_buf = None
         self._stream = None  # HIP stream handle for the per-step exchange kernels (None = the default stream)
@@ -363,9 +364,13 @@ class ParticleExchange:
 
     def _pdata_struct(self):
         A, m = self.arrays, _abi()
+        gen = getattr(A, "generation", None)  # changes whenever the device arrays are bound anew
+        if gen is not None and self._pdata_cache is not None and self._pdata_cache[0] == gen:
+            return self._pdata_cache[1]
         p = m.PDataArraysStruct()
         p.d_pos, p.d_vel, p.d_accel, p.d_image = A.pos.data_ptr(), A.vel.data_ptr(), A.accel.data_ptr(), A.image.data_ptr()
         p.d_tag, p.d_body, p.d_charge, p.d_diameter = A.tag.data_ptr(), A.body.data_ptr(), A.charge.data_ptr(), A.diameter.data_ptr()
+        self._pdata_cache = (gen, p)
         return p
 
     def _migrate_kernels(self):
