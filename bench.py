@@ -5,8 +5,9 @@ buffer = 0.4, dt = 0.005, fp64), cell list -> neighbor list -> LJ pair force -> 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" is one MD time step of the whole system.  W untimed steps (the lattice is melted under a
-Berendsen thermostat, then switched to NVE), then exactly K NVE steps are timed between
+One "step" is one MD time step of the whole system.  Every run first equilibrates, untimed and whatever W
+is: the lattice is melted under a Berendsen thermostat and switched to NVE for the last 200 of --equil
+steps (config.equilibration_steps).  Then W untimed warm-up steps, then exactly K NVE steps are timed between
 barrier + device synchronisation on both sides; the maximum over ranks is used.  With N > 1 GPUs the
 box is replicated per GPU (weak scaling) and split by spatial domain decomposition with a halo
 exchange over RCCL.  Rank 0 prints one JSON line.
@@ -14,7 +15,8 @@ exchange over RCCL.  Rank 0 prints one JSON line.
 `value` is particle-steps per second of the whole job; `timesteps_per_s` rides along.
 `roofline` prices the pair-force kernel: algorithmic bytes per launch = 4 * (listed neighbors) +
 76 * N, divided by the kernel's average duration measured with HIP events on the launch stream
-inside the timed region.  `cpu_baseline` times the CPU oracle (a C restatement of the reference's
+inside the timed region; `fp64_tflops` is 37 flop per listed pair (minimum image excluded: the tile path has
+none) over the same duration, next to the 78.6 TFLOP/s fp64 vector peak, so that an ALU-bound kernel shows.  `cpu_baseline` times the CPU oracle (a C restatement of the reference's
 CPU path: half neighbor list + Newton's third law) on a bounded sample, one replica per host core of
 this process's CPU share, all at the same time.
 """
@@ -30,6 +32,8 @@ for p in (ROOT, os.path.join(ROOT, "hoomd-blue_amd"), os.path.join(ROOT, "script
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector (non-matrix) peak
+FLOP_PER_LISTED_PAIR = 37.0  # dx (3), r^2 (5), cutoff test, LJ evaluator (~14 + 1 divide), 3 force FMAs, energy
 
 
 def grid_for(n):
@@ -106,6 +110,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--equil", type=int, default=2000,
+                    help="untimed equilibration steps before the warm-up: the lattice melts under the thermostat, the last 200 are NVE")
     ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpp", type=int, default=0)
@@ -180,12 +186,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up: melt under the thermostat (all but the last 200 steps), then NVE ----
-    melt = max(args.warmup - 200, 0) if args.warmup >= 400 else args.warmup // 2
+    # ---- equilibration (always, untimed): melt the lattice under the thermostat, then NVE; every buffer that grows
+    # with the liquid's neighbor counts (rows, cell slots, tile capacity) reaches its size here ----
+    melt = max(args.equil - 200, 0)
     sim.run(melt)
     if args.workload != "ka":
         method.thermostat = None  # the Kob-Andersen case keeps its thermostat, as the reference configuration does
-    sim.run(args.warmup - melt)
+    sim.run(args.equil - melt)
+    # ---- warm-up: W more steps of exactly what is timed ----
+    sim.run(args.warmup)
 
     # ---- timed region ----
     cell._cpp_obj.resetStats()
@@ -235,6 +244,7 @@ def main():
     avg_s = (ms / 1e3 / calls) if calls else float("nan")
     algo_bytes = 4.0 * listed + 76.0 * n_local
     achieved = algo_bytes / avg_s / 1e9 if calls else float("nan")
+    fp64_tflops = FLOP_PER_LISTED_PAIR * listed / avg_s / 1e12 if calls else float("nan")
 
     # HBM traffic of the pair-force kernel per launch from the L2 memory-side counters (FETCH_SIZE / WRITE_SIZE in
     # separate rocprofv3 --pmc passes, scripts/measure_traffic.sh): counters cannot be read from inside this
@@ -272,13 +282,14 @@ def main():
                              if args.workload == "kg" else
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
                              "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
-                "N": N_total, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
+                "N": N_total, "equilibration_steps": args.equil, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
                 "shortest_rebuild": int(cell.shortest_rebuild), "tile_capacity": int(cell._cpp_obj.tile_capacity), "mean_listed_neighbors": listed / max(n_local, 1),
             },
             "roofline": {
                 "kernel": "pair_force_tiles_kernel<EvaluatorPairLJ> (rank 0)" if cell._cpp_obj.tiles_active else "pair_force_kernel<EvaluatorPairLJ> (rank 0)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
+                "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "fp64_frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
