@@ -18,6 +18,7 @@
 // Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
 // following sum (the CPU path rounds every product and sum separately).
 #pragma clang fp contract(off)
+#include <mutex>
 #include "tile.cuh"
 
 namespace
@@ -721,6 +722,58 @@ extern "C" int hmd_nlist_build_head_list(const hmd_head_list_args_t* args, void*
     HMD_REQUIRE(args->d_workspace && args->workspace_bytes >= hmd_nlist_head_list_workspace_bytes(args->N), HMD_ERR_INVALID_ARGUMENT,
                 "hmd_nlist_build_head_list: workspace smaller than hmd_nlist_head_list_workspace_bytes(N)");
     unsigned long long* tiles = reinterpret_cast<unsigned long long*>(args->d_workspace);
+    hipLaunchKernelGGL(head_tile_sums_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, tiles, args->d_Nmax, args->d_pos, args->N);
+    hipLaunchKernelGGL(head_scan_tiles_kernel, dim3(1), dim3(HL_BLOCK), 0, s, tiles, ntiles, args->d_req_size_nlist);
+    hipLaunchKernelGGL(head_write_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, args->d_head_list, tiles, args->d_Nmax, args->d_pos, args->N);
+    return hmd_launch_status();
+    }
+
+// ---- the head list for callers that may not allocate ----
+// The tile sums of the scan live in a file-scope device array instead of a caller-provided workspace.
+// `scratch` names the array in device code only; host code uses the address hipGetSymbolAddress returned
+// for the current device (every GPU holds its own copy at its own address).
+constexpr unsigned int HL_NOALLOC_MAX_N = 1u << 24;
+constexpr unsigned int HL_NOALLOC_TILES = HL_NOALLOC_MAX_N / HL_TILE;
+static __device__ __align__(256) unsigned long long scratch[HL_NOALLOC_TILES + 1];
+constexpr int HL_NOALLOC_MAX_DEVICES = 64;
+static unsigned long long* g_hl_scratch[HL_NOALLOC_MAX_DEVICES];
+static std::mutex g_hl_scratch_mutex;
+
+extern "C" int hmd_nlist_build_head_list_noalloc(const hmd_head_list_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_build_head_list_noalloc: args is NULL");
+    HMD_REQUIRE(args->d_head_list && args->d_req_size_nlist && args->d_Nmax && args->d_pos, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nlist_build_head_list_noalloc: head_list, req_size_nlist, Nmax and pos are required");
+    HMD_REQUIRE(args->N <= HL_NOALLOC_MAX_N, HMD_ERR_TOO_LARGE,
+                "hmd_nlist_build_head_list_noalloc: N exceeds 16,777,216 particles, the size the static scratch array is built for "
+                "(use hmd_nlist_build_head_list with a workspace)");
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return (int)e;
+    HMD_REQUIRE(dev >= 0 && dev < HL_NOALLOC_MAX_DEVICES, HMD_ERR_TOO_LARGE, "hmd_nlist_build_head_list_noalloc: device ordinal above 63");
+    unsigned long long* tiles = nullptr;
+        {
+        std::lock_guard<std::mutex> lock(g_hl_scratch_mutex);
+        if (!g_hl_scratch[dev])
+            {
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p)
+                {
+                hmd_set_error("hmd_nlist_build_head_list_noalloc: hipGetSymbolAddress failed for the scratch array");
+                return e != hipSuccess ? (int)e : HMD_ERR_UNSUPPORTED;
+                }
+            g_hl_scratch[dev] = reinterpret_cast<unsigned long long*>(p);
+            }
+        tiles = g_hl_scratch[dev];
+        }
+    hipStream_t s = (hipStream_t)stream;
+    if (args->N == 0)
+        return (int)hipMemsetAsync(args->d_req_size_nlist, 0, sizeof(size_t), s);
+    // always the scan (also with one type, where the other entry point has a closed form): every tile sum
+    // the later kernels read is written by the first one, so the array's old contents never matter
+    const unsigned int ntiles = hmd_div_up(args->N, HL_TILE);
     hipLaunchKernelGGL(head_tile_sums_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, tiles, args->d_Nmax, args->d_pos, args->N);
     hipLaunchKernelGGL(head_scan_tiles_kernel, dim3(1), dim3(HL_BLOCK), 0, s, tiles, ntiles, args->d_req_size_nlist);
     hipLaunchKernelGGL(head_write_kernel, dim3(ntiles), dim3(HL_BLOCK), 0, s, args->d_head_list, tiles, args->d_Nmax, args->d_pos, args->N);

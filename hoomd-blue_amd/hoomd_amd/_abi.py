@@ -251,6 +251,7 @@ _SIGNATURES = {
     "hmd_nlist_needs_update_check": (C.c_int, [C.POINTER(NlistCheckArgs), vp]),
     "hmd_nlist_head_list_workspace_bytes": (C.c_size_t, [u32]),
     "hmd_nlist_build_head_list": (C.c_int, [C.POINTER(HeadListArgs), vp]),
+    "hmd_nlist_build_head_list_noalloc": (C.c_int, [C.POINTER(HeadListArgs), vp]),
     "hmd_compute_nlist_binned": (C.c_int, [C.POINTER(NlistBinnedArgs), vp]),
     "hmd_nlist_filter": (C.c_int, [C.POINTER(NlistFilterArgs), vp]),
     "hmd_update_exclusion_list": (C.c_int, [C.POINTER(UpdateExclusionArgs), vp]),

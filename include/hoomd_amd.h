@@ -201,6 +201,15 @@ typedef struct
     } hmd_head_list_args_t;
 int hmd_nlist_build_head_list(const hmd_head_list_args_t* args, void* stream);
 
+/* hmd_nlist_build_head_list without any allocation, for callers that cannot allocate device memory or ask
+   their caller for a workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
+   hipMalloc.  No counterpart in the reference.  d_workspace / workspace_bytes are ignored: the tile sums of
+   the scan live in a static device array inside the library (64 KiB per GPU, held until the process
+   ends), sized for N <= 16,777,216; a larger N returns HMD_ERR_TOO_LARGE.  Same outputs as
+   hmd_nlist_build_head_list.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+   (different streams or host threads) race and must be serialised by the caller. */
+int hmd_nlist_build_head_list_noalloc(const hmd_head_list_args_t* args, void* stream);
+
 /* Replaces gpu_compute_nlist_binned (hoomd/md/NeighborListGPUBinned.cuh:35-62,
    hoomd/md/NeighborListGPUBinned.cu:756-823).  Full neighbor list only (as the reference's GPU
    class, hoomd/md/NeighborListGPUBinned.cc:51-54).  For every owned particle i: all j != i in the
