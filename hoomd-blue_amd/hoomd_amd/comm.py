@@ -171,6 +171,26 @@ class DomainDecomposition:
             raise ValueError(f"grid {self.grid} does not match {self.world} ranks")
         self.communicator = None
         self._sim = None
+        self._shares_gpu = None
+
+    def ranks_share_a_gpu(self):
+        """True when two ranks of the group run on the same GPU (rehearsals and tests; production is one rank per
+        GPU).  Every rank gets the same answer: (host name, PCI bus id of the current device) of all ranks are
+        gathered once.  The neighbor list then keeps its exchange stream at normal priority: with more processes on
+        a GPU than it has hardware queues, a high-priority queue waiting for an event of a normal-priority queue
+        keeps the scheduler from ever running the latter."""
+        if self._shares_gpu is None:
+            import socket
+            me = None
+            if torch.cuda.is_available():
+                p = torch.cuda.get_device_properties(torch.cuda.current_device())
+                ident = getattr(p, "uuid", None) or getattr(p, "pci_bus_id", None)
+                me = (socket.gethostname(), str(ident) if ident is not None else f"ordinal {torch.cuda.current_device()}")
+            ids = [None] * self.world
+            dist.all_gather_object(ids, me, group=self.group)
+            ids = [i for i in ids if i is not None]
+            self._shares_gpu = len(set(ids)) < len(ids)
+        return self._shares_gpu
 
     # ---- geometry ----
     def _set_box(self, L, lo, twod=False):
@@ -229,6 +249,8 @@ class DomainDecomposition:
 
     def _nlist_attached(self, nlist):
         self.communicator.nlists.append(nlist)
+        if nlist._cpp_obj is not None and self.ranks_share_a_gpu():
+            nlist._cpp_obj.comm_stream_high_priority = False
 
     def _allreduce_sum_list(self, values):
         ex = self.communicator.exchange if self.communicator is not None else None
@@ -340,13 +362,29 @@ class ParticleExchange:
         self._init_buf = None
         self._plan_buf = None
         self._stream = None  # HIP stream handle for the per-step exchange kernels (None = the default stream)
+        self._pinned = {}
 
     # ---- collectives ----
+    def _pinned_like(self, name, t):
+        """A pinned host tensor of t's shape and dtype, carved from a buffer that is kept between calls."""
+        nbytes = t.numel() * t.element_size()
+        buf = self._pinned.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
+            self._pinned[name] = buf
+        return buf[:nbytes].view(t.dtype).view(t.shape)
+
     def _a2a(self, out, inp, out_splits, in_splits):
-        if self._stage:  # gloo cannot move device memory: stage through the host (tests only)
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.dd.group)
-            out.copy_(o)
+        if self._stage:
+            # gloo cannot move device memory (tests only): stage through pinned host buffers with asynchronous copies on
+            # the stream the exchange kernels run on, and wait for exactly that stream
+            stream = torch.cuda.current_stream(self.device)
+            hin, hout = self._pinned_like("in", inp), self._pinned_like("out", out)
+            hin.copy_(inp, non_blocking=True)
+            stream.synchronize()
+            dist.all_to_all_single(hout, hin, out_splits, in_splits, group=self.dd.group)
+            out.copy_(hout, non_blocking=True)
+            stream.synchronize()  # the buffers are reused by the next call
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.dd.group)
 
@@ -793,10 +831,14 @@ class Communicator(_cpp.Communicator):
                 self._vote = (word, int(checkn))
                 return int(d_flag)
             ex.update_ghosts()
-        if ex._stage:  # gloo rehearsal on device memory: reduce through the host
-            v = word.cpu()
+        if ex._stage:  # gloo rehearsal on device memory: reduce through a pinned host word
+            stream = torch.cuda.current_stream(ex.device)
+            v = ex._pinned_like("vote", word)
+            v.copy_(word, non_blocking=True)
+            stream.synchronize()
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.dd.group)
-            word.copy_(v)
+            word.copy_(v, non_blocking=True)
+            stream.synchronize()
         else:
             dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.dd.group)
         self._vote = (word, int(checkn))

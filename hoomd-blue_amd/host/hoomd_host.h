@@ -141,6 +141,12 @@ class PinnedWords
     unsigned int* m_d = nullptr;
     };
 
+//! Spins until the 8-byte word at `h` (mapped pinned memory a kernel stores to) carries `stamp` in its upper half and
+//! returns the word.  The default stream and `other` (when not null) are probed for errors while waiting, and after a
+//! wall-clock limit (HOOMD_AMD_POLL_TIMEOUT_S, default 120 s) the wait ends in a std::runtime_error that names `what`,
+//! the stamp and which of the streams still had work queued, so a stuck exchange ends the process instead of spinning.
+unsigned long long pollStampedWord(volatile unsigned long long* h, unsigned int stamp, const char* what, hipStream_t other = nullptr);
+
 //! Reads a few device words without a stream synchronisation: a one-wave kernel queued behind the producer
 //! stores them, stamped, to mapped pinned memory that the host polls (hmd_publish_words).
 class WordReadback
@@ -1004,6 +1010,20 @@ class NeighborListGPUBinned : public Compute
         {
         return m_n_overlapped;
         }
+    //! Priority of the stream the halo exchange runs on beside the interior force launch.  High (the default) keeps
+    //! the exchange's small kernels on a hardware queue of their own.  It must be normal when several processes
+    //! share this GPU: their queues then outnumber the hardware's, the scheduler maps queues by priority, and a
+    //! high-priority queue that waits for an event of its own process's normal-priority queue keeps that queue
+    //! (and everyone else's) from ever running.  Takes effect when the stream is created (first overlapped step).
+    void setCommStreamHighPriority(bool high)
+        {
+        m_comm_high_priority = high;
+        }
+    bool getCommStreamHighPriority() const
+        {
+        return m_comm_high_priority;
+        }
+
     //! time step of the last (re)build
     uint64_t getLastBuildTimestep() const
         {
@@ -1080,6 +1100,7 @@ class NeighborListGPUBinned : public Compute
     hipStream_t m_comm_stream = nullptr;
     hipEvent_t m_ev_ready = nullptr, m_ev_comm = nullptr;
     bool m_overlap = true;
+    bool m_comm_high_priority = true;
     uint64_t m_n_overlapped = 0;
     WordReadback m_readback;
     bool m_in_compute = false;

@@ -338,6 +338,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property_readonly("tile_capacity", &NeighborListGPUBinned::getTileCapacity)
         .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)
         .def_property_readonly("num_overlapped", &NeighborListGPUBinned::getNumOverlapped)
+        .def_property("comm_stream_high_priority", &NeighborListGPUBinned::getCommStreamHighPriority, &NeighborListGPUBinned::setCommStreamHighPriority)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)
         .def("setFilterBody", &NeighborListGPUBinned::setFilterBody)

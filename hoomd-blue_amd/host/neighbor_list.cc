@@ -245,14 +245,18 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
             {
             if (!m_comm_stream)
                 {
-                // highest priority: the runtime keeps such streams on hardware queues of their own, so the
-                // exchange's small kernels are not lined up behind the force kernel of the default stream
-                // (HOOMD_AMD_COMM_PRIORITY=normal: for several processes sharing one GPU, whose high-priority
-                // queues waiting on their normal-priority ones can starve each other)
+                // highest priority (unless the communicator found several ranks on this GPU, see
+                // setCommStreamHighPriority): the runtime keeps such streams on hardware queues of their own, so the
+                // exchange's small kernels are not lined up behind the force kernel of the default stream.
+                // HOOMD_AMD_COMM_PRIORITY=normal|high overrides the choice (experiments).
                 int least = 0, greatest = 0;
                 hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
                 const char* prio = std::getenv("HOOMD_AMD_COMM_PRIORITY");
-                const bool high = !(prio && std::string(prio) == "normal");
+                bool high = m_comm_high_priority;
+                if (prio && std::string(prio) == "normal")
+                    high = false;
+                else if (prio && std::string(prio) == "high")
+                    high = true;
                 hipCheck(hipStreamCreateWithPriority(&m_comm_stream, hipStreamNonBlocking, high ? greatest : 0), "hipStreamCreateWithPriority");
                 hipCheck(hipEventCreateWithFlags(&m_ev_ready, hipEventDisableTiming), "hipEventCreateWithFlags");
                 hipCheck(hipEventCreateWithFlags(&m_ev_comm, hipEventDisableTiming), "hipEventCreateWithFlags");
@@ -286,20 +290,7 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
                 }
             else if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn)))
                 abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, nullptr), "hmd_publish_word");
-            unsigned long long v = 0;
-            for (uint64_t spins = 0;; spins++)
-                {
-                v = *hv;
-                if ((unsigned int)(v >> 32) == m_checkn)
-                    break;
-                __builtin_ia32_pause();
-                if ((spins & 0xfffff) == 0xfffff)
-                    {
-                    hipError_t q = hipStreamQuery(0);
-                    if (q != hipSuccess && q != hipErrorNotReady)
-                        hipCheck(q, "rebuild vote");
-                    }
-                }
+            const unsigned long long v = pollStampedWord(hv, m_checkn, "rebuild vote", overlapped ? m_comm_stream : nullptr);
             return (unsigned int)v == m_checkn;
             }
         }
@@ -314,21 +305,7 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
     else
         abiCheck(hmd_publish_word(m_flag.get(), reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16), m_checkn, nullptr),
                  "hmd_publish_word");
-    unsigned long long v = 0;
-    for (uint64_t spins = 0;; spins++)
-        {
-        v = *h;
-        if ((unsigned int)(v >> 32) == m_checkn)
-            break;
-        __builtin_ia32_pause();
-        if ((spins & 0xfffff) == 0xfffff)
-            {
-            // surfaces a faulted kernel instead of spinning forever
-            hipError_t q = hipStreamQuery(0);
-            if (q != hipSuccess && q != hipErrorNotReady)
-                hipCheck(q, "distance check");
-            }
-        }
+    const unsigned long long v = pollStampedWord(h, m_checkn, "distance check");
     bool result = ((unsigned int)v == m_checkn);
     if (m_sysdef->isDomainDecomposed())
         result = m_sysdef->getCommunicator()->anyRank(result);

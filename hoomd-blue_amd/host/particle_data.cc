@@ -1,6 +1,9 @@
 // particle_data.cc -- ParticleData, ParticleGroup, Compute and small utilities of the host layer.
 #include "hoomd_host.h"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 
@@ -51,23 +54,54 @@ void WordReadback::read(const unsigned int* d_words, unsigned int n, unsigned in
     abiCheck(hmd_publish_words(d_words, n, reinterpret_cast<unsigned long long*>(m_pinned.deviceView()), m_stamp, nullptr), "hmd_publish_words");
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_pinned.get());
     for (unsigned int k = 0; k < n; k++)
+        out[k] = (unsigned int)pollStampedWord(h + k, m_stamp, what);
+    }
+
+unsigned long long pollStampedWord(volatile unsigned long long* h, unsigned int stamp, const char* what, hipStream_t other)
+    {
+    static const double limit_s = []()
+    {
+        const char* e = std::getenv("HOOMD_AMD_POLL_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
+    for (uint64_t spins = 0;; spins++)
         {
-        unsigned long long v = 0;
-        for (uint64_t spins = 0;; spins++)
+        const unsigned long long v = *h;
+        if ((unsigned int)(v >> 32) == stamp)
+            return v;
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff)
             {
-            v = h[k];
-            if ((unsigned int)(v >> 32) == m_stamp)
-                break;
-            __builtin_ia32_pause();
-            if ((spins & 0xfffff) == 0xfffff)
+            // surfaces a faulted kernel on either stream instead of spinning forever
+            const hipError_t q0 = hipStreamQuery(0);
+            if (q0 != hipSuccess && q0 != hipErrorNotReady)
+                hipCheck(q0, what);
+            hipError_t q1 = hipSuccess;
+            if (other)
                 {
-                // surfaces a faulted kernel instead of spinning forever
-                hipError_t q = hipStreamQuery(0);
-                if (q != hipSuccess && q != hipErrorNotReady)
-                    hipCheck(q, what);
+                q1 = hipStreamQuery(other);
+                if (q1 != hipSuccess && q1 != hipErrorNotReady)
+                    hipCheck(q1, what);
+                }
+            const auto now = std::chrono::steady_clock::now();
+            if (!timing)
+                {
+                t0 = now;
+                timing = true;
+                }
+            else if (std::chrono::duration<double>(now - t0).count() > limit_s)
+                {
+                std::ostringstream oss;
+                oss << what << ": word with stamp " << stamp << " did not arrive within " << limit_s << " s (last stamp seen "
+                    << (unsigned int)(v >> 32) << "); default stream " << (q0 == hipSuccess ? "idle" : "busy");
+                if (other)
+                    oss << ", exchange stream " << (q1 == hipSuccess ? "idle" : "busy");
+                throw std::runtime_error(oss.str());
                 }
             }
-        out[k] = (unsigned int)v;
         }
     }
 

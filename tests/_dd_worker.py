@@ -51,11 +51,6 @@ def main():
     n = tuple(int(v) for v in sys.argv[8:11])
     steps = int(sys.argv[11])
     sorter = bool(int(sys.argv[12]))
-    if world > 1:
-        # Several processes share one GPU here.  Their high-priority queues, each waiting for an event of the
-        # same process's normal-priority queue, were seen to starve each other (runs hung now and then);
-        # with one process per GPU, as in production, there is no such competition.
-        os.environ["HOOMD_AMD_COMM_PRIORITY"] = "normal"
     import hoomd_amd as hoomd
     dd = None
     if world > 1:
@@ -66,9 +61,22 @@ def main():
     torch.cuda.set_device(0)
     sim, cell, lj, thermo = build(hoomd, dd, n, steps, sorter)
     sim.run(0)
+    if dd is not None:
+        # a stuck run says which stream holds unfinished work before the launcher's limit ends it
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(25.0):
+                side = dd.communicator._side
+                print(f"[watchdog rank {rank}] step {sim.timestep}: default stream idle={torch.cuda.default_stream().query()}, "
+                      f"exchange stream idle={side[1].query() if side else None}", flush=True)
+        threading.Thread(target=watchdog, daemon=True).start()
     e0 = (thermo.kinetic_energy, thermo.potential_energy)
     sim.run(steps)
     e1 = (thermo.kinetic_energy, thermo.potential_energy)
+    if dd is not None:
+        done.set()
     s = sim.state.get_snapshot()
     dof = thermo.degrees_of_freedom  # collective under domain decomposition: every rank asks
     stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds),
