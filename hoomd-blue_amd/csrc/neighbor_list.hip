@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
 __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
                                                                 unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
-                                                                unsigned int* d_slot_of, hmd_scalar4* d_cpos)
+                                                                unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group, unsigned int row_pieces)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
@@ -148,6 +148,10 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         s_shift[3 * lane + 2] = sz;
         }
     unsigned int tile_pad = 0; // what pads a tile row: the slot of the consumers' dummy candidate
+    // tile rows: number of the home cell's first member among the home particles of its block, the block's
+    // first group of rows, and the most entries a row has room for
+    unsigned int tile_hoff = 0, tile_grp0 = 0;
+    const unsigned int tile_row_cap = row_pieces * hmd::TL_PIECE;
     if (TILE)
         {
         const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
@@ -157,14 +161,30 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         const int rcell = (int)lane < hmd::TL_RC ? hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg) : -1;
         const unsigned int rsize = rcell >= 0 ? min(a.d_cell_size[rcell], a.cli.w) : 0u;
         const unsigned int rincl = hmd::tile_wave_scan(rsize, (int)lane);
-        // d_tile_overflow[0]: a region outgrew the tile; [1]: largest region population seen (what the
-        // consumers of these rows need as LDS capacity)
+        // d_tile_overflow[0]: a region outgrew the tile, or the rows need more groups than there is room for (set by
+        // the kernel that numbers the groups); [1]: largest region population seen (what the consumers of these rows
+        // need as LDS capacity)
         const unsigned int rtotal = rl_u(rincl, 63);
-        if (rtotal > tile_capacity)
+        if (rtotal > tile_capacity || __builtin_amdgcn_readfirstlane(d_tile_overflow[0]) != 0u)
             {
             if (lane == 0)
                 d_tile_overflow[0] = 1u;
             return;
+            }
+            {
+            const unsigned int nbx = (a.ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (a.ci.h + hmd::TB_Y - 1) / hmd::TB_Y;
+            const unsigned int tb = ((unsigned int)(c0[2] / hmd::TB_Z) * nby + (unsigned int)(c0[1] / hmd::TB_Y)) * nbx + (unsigned int)(c0[0] / hmd::TB_X);
+            tile_grp0 = __builtin_amdgcn_readfirstlane(d_block_group[tb]);
+            const int my_hc = ((hc[2] - c0[2]) * hmd::TB_Y + (hc[1] - c0[1])) * hmd::TB_X + (hc[0] - c0[0]);
+#pragma unroll
+            for (int q = 0; q < hmd::TL_NH; q++)
+                {
+                const int qx = q % hmd::TB_X, qy = (q / hmd::TB_X) % hmd::TB_Y, qz = q / (hmd::TB_X * hmd::TB_Y);
+                const bool home = c0[0] + qx < dim[0] && c0[1] + qy < dim[1] && c0[2] + qz < dim[2];
+                const unsigned int sz = rl_u(rsize, (unsigned int)hmd::tile_home_rc(q));
+                if (q < my_hc && home)
+                    tile_hoff += sz;
+                }
             }
         if (lane == 0 && sub == 0 && rtotal > d_tile_overflow[1])
             atomicMax(d_tile_overflow + 1, rtotal);
@@ -286,6 +306,14 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (FILTER_BODY)
                     body_i = rl_u(hbody, iu);
                 unsigned int* row = a.d_nlist + head_i;
+                unsigned short* trow = nullptr;
+                unsigned int nmax_w = nmax_i;
+                if (TILE)
+                    {
+                    const unsigned int h_i = tile_hoff + hbase + iu;
+                    trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
+                    nmax_w = min(nmax_i, tile_row_cap);
+                    }
 
 #pragma unroll
                 for (int c = 0; c < NL_MAXK; c++)
@@ -306,10 +334,10 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         if (mask)
                             {
                             const unsigned int pos = cnt_i + hmd_rank_in_mask(mask);
-                            if (hit && pos < nmax_i)
+                            if (hit && pos < nmax_w)
                                 {
                                 if (TILE)
-                                    (d_tile + head_i)[pos] = (unsigned short)cl[c];
+                                    trow[((pos & ~15u) << 4) | (pos & 15u)] = (unsigned short)cl[c];
                                 else
                                     row[pos] = cj[c];
                                 }
@@ -338,7 +366,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             {
             if (TILE && d_slot_meta)
                 {
-                hmd_uint4 m = {hidx, cnt, (unsigned int)(hhead / 4), 0u};
+                hmd_uint4 m = {hidx, cnt, 0u, 0u};
                 const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
                 d_slot_meta[w] = m;
                 if (d_slot_of)
@@ -350,8 +378,12 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 }
             a.d_n_neigh[hidx] = cnt;
             if (TILE)
-                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < hnmax; k++)
-                    (d_tile + hhead)[k] = (unsigned short)tile_pad;
+                {
+                const unsigned int h_i = tile_hoff + hbase + lane;
+                unsigned short* trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
+                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < min(hnmax, tile_row_cap); k++)
+                    trow[((k & ~15u) << 4) | (k & 15u)] = (unsigned short)tile_pad;
+                }
             if (a.d_last_updated_pos)
                 {
                 // same bits as pos[hidx]: the cell list holds a copy of x,y,z and of the type id
@@ -535,10 +567,65 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
         a.d_ex_list_idx[hmd_idx2(a.ex_list_indexer, idx, o)] = a.d_rtag[a.d_ex_list_tag[hmd_idx2(a.ex_list_tag_indexer, tag, o)]];
     }
 
+// Numbers the groups of tile rows: block b (2x2x2 cells) gets ceil(members of its home cells / 16) groups starting at
+// d_block_group[b]; d_block_group[number of blocks] = all groups.  One workgroup: every thread sums a run of
+// consecutive blocks, the runs are scanned, every thread writes its run.
+constexpr unsigned int BG_THREADS = 1024;
+__global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const unsigned int* d_cell_size, hmd_index3d_t ci, unsigned int cell_Nmax,
+                                                                       unsigned int* d_block_group, unsigned int tile_groups, unsigned int* d_tile_overflow)
+    {
+    __shared__ unsigned int s_wave[BG_THREADS / 64];
+    const unsigned int nbx = (ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (ci.h + hmd::TB_Y - 1) / hmd::TB_Y, nbz = (ci.d + hmd::TB_Z - 1) / hmd::TB_Z;
+    const unsigned int nb = nbx * nby * nbz;
+    const unsigned int per = (nb + BG_THREADS - 1) / BG_THREADS;
+    const unsigned int first = min(threadIdx.x * per, nb), last = min(first + per, nb);
+    auto groups_of = [&](unsigned int b) -> unsigned int
+    {
+        const unsigned int cx0 = hmd::TB_X * (b % nbx), cy0 = hmd::TB_Y * ((b / nbx) % nby), cz0 = hmd::TB_Z * (b / (nbx * nby));
+        unsigned int members = 0;
+#pragma unroll
+        for (int q = 0; q < hmd::TL_NH; q++)
+            {
+            const unsigned int x = cx0 + q % hmd::TB_X, y = cy0 + (q / hmd::TB_X) % hmd::TB_Y, z = cz0 + q / (hmd::TB_X * hmd::TB_Y);
+            if (x < ci.w && y < ci.h && z < ci.d)
+                members += min(d_cell_size[(z * ci.h + y) * ci.w + x], cell_Nmax);
+            }
+        return (members + hmd::TL_GROUP - 1) / hmd::TL_GROUP;
+    };
+    unsigned int mine = 0;
+    for (unsigned int b = first; b < last; b++)
+        mine += groups_of(b);
+    // exclusive scan over the threads
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int incl = hmd::tile_wave_scan(mine, (int)lane);
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int base = 0, total = 0;
+    for (unsigned int w = 0; w < BG_THREADS / 64; w++)
+        {
+        if (w < wave)
+            base += s_wave[w];
+        total += s_wave[w];
+        }
+    unsigned int run = base + incl - mine;
+    for (unsigned int b = first; b < last; b++)
+        {
+        d_block_group[b] = run;
+        run += groups_of(b);
+        }
+    if (threadIdx.x == 0)
+        {
+        d_block_group[nb] = total;
+        if (total > tile_groups)
+            d_tile_overflow[0] = 1u;
+        }
+    }
+
 template<bool ST, bool FB>
 int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
                  unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr,
-                 unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr)
+                 unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr, const unsigned int* d_block_group = nullptr, unsigned int row_pieces = 0)
     {
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const dim3 grid(hmd_div_up(ncells, cells_per_block));
@@ -551,19 +638,20 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     if (d_tile)
         {
         HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
         }
     else if (fixed_images)
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
     else if (hmd_box_is_ortho(a.box))
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
     else
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
     return hmd_launch_status();
     }
 
 int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow,
-                        hmd_uint4* d_slot_meta, unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr)
+                        hmd_uint4* d_slot_meta, unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr, const unsigned int* d_block_group = nullptr,
+                        unsigned int row_pieces = 0)
     {
     const bool single = (a.ntypes == 1);
     const bool fb = a.filter_body != 0;
@@ -576,12 +664,12 @@ int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigne
         wpc = 4;
     const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
     if (single && !fb)
-        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
     if (single && fb)
-        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
     if (!single && !fb)
-        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
-    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos);
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
     }
     } // namespace
 
@@ -652,8 +740,26 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     a.r_buff = t.r_buff;
     a.ntypes = t.ntypes;
     HMD_REQUIRE(!t.d_slot_of || (t.d_slot_meta && t.geom.d_cpos), HMD_ERR_INVALID_ARGUMENT, "hmd_compute_nlist_tiles: d_slot_of needs d_slot_meta and geom.d_cpos");
+    HMD_REQUIRE(t.geom.d_block_group && t.geom.row_pieces >= 1, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_tiles: geom.d_block_group and geom.row_pieces are required");
+    const size_t groups_fit = t.tile_nlist_entries / hmd::tile_group_entries(t.geom.row_pieces);
+    HMD_REQUIRE(groups_fit > hmd::TL_SLACK_GROUPS && groups_fit - hmd::TL_SLACK_GROUPS <= 0xffffffffull, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_tiles: tile_nlist_entries holds no group of rows (size it with hmd_nlist_tiles_storage_entries)");
+    const unsigned int tile_groups = (unsigned int)(groups_fit - hmd::TL_SLACK_GROUPS);
+    // the caller clears d_tile_overflow; the groups are numbered first, and the build gives up when they do not fit
+    hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci, t.geom.cli.w,
+                       const_cast<unsigned int*>(t.geom.d_block_group), tile_groups, t.d_tile_overflow);
     return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta, t.d_slot_of,
-                               t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr);
+                               t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr, t.geom.d_block_group, t.geom.row_pieces);
+    }
+
+extern "C" size_t hmd_nlist_tiles_storage_entries(const hmd_index3d_t* ci, unsigned int n_members, unsigned int row_pieces)
+    {
+    if (!ci)
+        return 0;
+    // every block rounds its members up to whole groups
+    const size_t groups = (size_t)n_members / hmd::TL_GROUP + hmd::tile_num_blocks(*ci) + 1 + hmd::TL_SLACK_GROUPS;
+    return groups * hmd::tile_group_entries(row_pieces);
     }
 
 extern "C" int hmd_nlist_needs_update_check(const hmd_nlist_check_args_t* args, void* stream)

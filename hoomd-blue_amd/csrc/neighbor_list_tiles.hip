@@ -16,29 +16,36 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
     extern __shared__ __align__(16) unsigned char s_dyn[];
     unsigned int* tidx = reinterpret_cast<unsigned int*>(s_dyn);
     int cx0, cy0, cz0;
-    tile_setup(a.geom, a.box, T, cx0, cy0, cz0);
+    const unsigned int vb = tile_xcd_remap(blockIdx.x, gridDim.x);
+    tile_setup(a.geom, a.box, T, cx0, cy0, cz0, vb);
     __syncthreads();
     if (T.off[64] > a.geom.capacity)
         return;
     tile_stage<false, true, false>(a.geom, a.box, T, nullptr, nullptr, nullptr, nullptr, tidx, nullptr);
     __syncthreads();
     const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    const unsigned int grp0 = a.geom.d_block_group[vb];
+    unsigned int hfirst = 0; // number of the home cell's first member among the block's home particles
     for (unsigned int hc = 0; hc < (unsigned int)TL_NH; hc++)
         {
         const int hx = hc % TB_X, hy = (hc / TB_X) % TB_Y, hz = hc / (TB_X * TB_Y);
         if (!tile_is_home(a.geom, cx0, cy0, cz0, hx, hy, hz))
             continue;
         const unsigned int rc_home = tile_home_rc((int)hc);
-        for (unsigned int lh = T.off[rc_home] + wave; lh < T.off[rc_home + 1]; lh += 4)
+        const unsigned int n_cell = T.off[rc_home + 1] - T.off[rc_home];
+        for (unsigned int s = wave; s < n_cell; s += 4)
             {
-            const unsigned int i = tidx[lh];
+            const unsigned int i = tidx[T.off[rc_home] + s];
             if (i >= a.N)
                 continue;
-            const unsigned int n = a.d_n_neigh[i];
+            const unsigned int h = hfirst + s;
+            const unsigned short* trow = a.d_tile_nlist + (size_t)(grp0 + h / TL_GROUP) * tile_group_entries(a.geom.row_pieces) + (h % TL_GROUP) * TL_PIECE;
+            const unsigned int n = min(a.d_n_neigh[i], a.geom.row_pieces * TL_PIECE);
             const size_t head = a.d_head_list[i];
             for (unsigned int k = lane; k < n; k += 64)
-                a.d_nlist[head + k] = tidx[tile_unslot(a.d_tile_nlist[head + k])];
+                a.d_nlist[head + k] = tidx[tile_unslot(trow[((k & ~15u) << 4) | (k & 15u)])];
             }
+        hfirst += n_cell;
         }
     }
 
@@ -93,7 +100,8 @@ extern "C" int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, voi
     {
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_to_rows: args is NULL");
     const hmd_tiles_to_rows_args_t& a = *args;
-    HMD_REQUIRE(a.geom.d_cell_size && a.geom.d_cell_idx && a.d_tile_nlist && a.d_n_neigh && a.d_head_list && a.d_nlist,
+    HMD_REQUIRE(a.geom.d_cell_size && a.geom.d_cell_idx && a.d_tile_nlist && a.d_n_neigh && a.d_head_list && a.d_nlist && a.geom.d_block_group
+                    && a.geom.row_pieces >= 1,
                 HMD_ERR_INVALID_ARGUMENT, "hmd_nlist_tiles_to_rows: a required array is NULL");
     unsigned int cap = 0;
     const int rc = hmd_nlist_tiles_supported(&a.geom.ci, &a.box, a.geom.cli.w, 1, &cap);

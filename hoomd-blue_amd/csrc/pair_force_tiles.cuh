@@ -1,9 +1,13 @@
 // pair_force_tiles.cuh -- pair forces from LDS tiles.
 //
 // Same per-pair arithmetic and outputs as pair_force.cuh (hoomd/md/PotentialPairGPU.cuh:140-404); the
-// neighbor rows hold 16-bit candidate numbers of the workgroup's region (tile.cuh), so a neighbor's
-// coordinates are three LDS reads and the periodic image is already applied.  TPP lanes share a
-// home particle; each lane takes four consecutive row entries (one 8-byte load) per trip.
+// neighbor rows hold 16-bit tile slots of the workgroup's region (tile.cuh), so a neighbor's
+// coordinates are three LDS reads and the periodic image is already applied.  Four lanes share a
+// home particle and a wave works on the sixteen home particles of one group of rows at a time: rows are
+// stored neighbor-major within a group (tile.cuh, TL_GROUP / TL_PIECE), so every trip of the wave is one
+// 512-byte load, each lane taking four consecutive entries of its particle's row.  A wave's trip count is
+// that of the longest of its sixteen rows, whatever the lengths of the others, and what is left per home
+// particle is one read of the home table and a two-step reduction over four lanes.
 // Row entries are tile slots (tile_slot() in tile.cuh): 8 * entry is the byte offset of x in the tile,
 // y and z follow 256 and 512 bytes later.
 #ifndef HMD_PAIR_FORCE_TILES_CUH
@@ -18,13 +22,12 @@ namespace hmd
 struct pft_home_t
     {
     unsigned int idx;
-    unsigned int row;   // offset of the particle's row in d_tile_nlist, in units of four entries
     unsigned int nn_lh; // low half: number of neighbors; high half: tile slot of the particle itself
     };
-static_assert(sizeof(pft_home_t) == 12, "LDS budget");
-__device__ __forceinline__ pft_home_t pft_home(unsigned int idx, unsigned int nn, unsigned int row, unsigned int lh)
+static_assert(sizeof(pft_home_t) == 8, "LDS budget");
+__device__ __forceinline__ pft_home_t pft_home(unsigned int idx, unsigned int nn, unsigned int lh)
     {
-    pft_home_t e = {idx, row, min(nn, 0xffffu) | (lh << 16)};
+    pft_home_t e = {idx, min(nn, 0xffffu) | (lh << 16)};
     return e;
     }
 
@@ -35,6 +38,32 @@ __host__ __device__ constexpr size_t pft_home_bytes(unsigned int cell_Nmax)
     }
 
 typedef __attribute__((address_space(3))) const double pft_lds_double;
+
+// position (and type id when asked for) of one slot of the slot-ordered position copy
+struct pft_pos
+    {
+    double x, y, z;
+    unsigned int t;
+    };
+template<bool WITH_TYPE> __device__ __forceinline__ pft_pos pft_ld_pos(const hmd_scalar4* p)
+    {
+    pft_pos r;
+    const double2 xy = *reinterpret_cast<const double2*>(p);
+    r.x = xy.x;
+    r.y = xy.y;
+    if (WITH_TYPE)
+        {
+        const double2 zw = reinterpret_cast<const double2*>(p)[1];
+        r.z = zw.x;
+        r.t = hmd_double_as_uint(zw.y);
+        }
+    else
+        {
+        r.z = reinterpret_cast<const double*>(p)[2];
+        r.t = 0;
+        }
+    return r;
+    }
 
 // byte offset 8 * (16-bit half of w) in one instruction
 template<int HALF> __device__ __forceinline__ unsigned int pft_slot_bytes(unsigned int w, unsigned int three)
@@ -48,14 +77,74 @@ template<int HALF> __device__ __forceinline__ unsigned int pft_slot_bytes(unsign
     }
 
 constexpr int PFT_THREADS = 256;              // 4 waves share one staged region
-constexpr size_t PFT_TABLES = (sizeof(tile_tables) + 16 + 15) / 16 * 16; // tile_tables and the shared home counter
+constexpr int PFT_T = 4;                      // lanes per home particle: 64 / PFT_T = TL_GROUP home particles per wave
+constexpr int PFT_PRE = 6;                    // pieces of every row (96 entries) fetched one group ahead
+static_assert(64 / PFT_T == (int)TL_GROUP && PFT_T * 4 == (int)TL_PIECE, "a wave reads one piece of each of its sixteen rows per trip");
 constexpr int PFT_WAVES = PFT_THREADS / 64;
-constexpr int PFT_CELLS = (TL_RC + PFT_WAVES - 1) / PFT_WAVES; // region cells staged by one wave
-constexpr int PFT_BATCH = (PFT_CELLS + 1) / 2;                  // ... in two rounds of this many loads in flight
+constexpr int PFT_TRIPS = 4;
+static_assert(TR_X == 4 && TR_Y == 4 && TR_Z == 4 && PFT_WAVES == 4 && TL_NH == 8, "staging maps (lane / 16, wave, trip) to the cells of a 4x4x4 region");
 
-template<class Ev, unsigned int SHIFT, bool VIRIAL, int TPP, bool SINGLE_TYPE>
-__global__ void __launch_bounds__(PFT_THREADS)
-    pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params)
+// what the workgroup shares besides the tile and the home table
+struct pft_tables
+    {
+    unsigned int off[65];         // exclusive prefix of the region's cell sizes; off[64] = total
+    unsigned int hcum[TL_NH + 1]; // exclusive prefix of the sizes of the home cells, in home-cell order; hcum[8] = home particles
+    unsigned int word;            // the predicate word, read once for the whole workgroup
+    unsigned int pad_;
+    };
+constexpr size_t PFT_TABLES = (sizeof(pft_tables) + 15) / 16 * 16;
+
+// launch helpers computed on the host (not part of the C ABI): the grid of blocks and reciprocals, so that no
+// integer or fp64 division runs on the device (q = n * ceil(2^40 / d) >> 40 is exact for n < 2^24, d < 2^16)
+struct pft_launch_t
+    {
+    unsigned int nbx, nby;
+    unsigned long long inv_nbx, inv_nby;
+    double inv_dim[3];
+    };
+
+// one axis of a region cell: grid coordinate (wrapped along a periodic axis), the image it is seen in, whether
+// it exists, and whether a member may have been wrapped by the integrator since binning (only members of the
+// first and last cells along a periodic axis can cross the box boundary between two builds)
+struct pft_axis
+    {
+    int c, img;
+    bool valid, edge;
+    };
+__device__ __forceinline__ pft_axis pft_axis_cell(int c, int dim, bool periodic)
+    {
+    pft_axis r = {c, 0, true, false};
+    if (c < 0)
+        {
+        if (periodic)
+            {
+            r.c = c + dim;
+            r.img = -1;
+            }
+        else
+            r.valid = false;
+        }
+    else if (c >= dim)
+        {
+        if (periodic)
+            {
+            r.c = c - dim;
+            r.img = 1;
+            }
+        else
+            r.valid = false;
+        }
+    // a region wider than the grid would wrap twice: such a cell is no neighbor of any home cell
+    if (r.c < 0 || r.c >= dim)
+        r.valid = false;
+    r.edge = periodic && (r.c == 0 || r.c == dim - 1);
+    return r;
+    }
+
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE>
+__global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
+    pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params,
+                            pft_launch_t lp)
     {
     typedef typename Ev::param_type param_t;
     // All LDS of this kernel is dynamic and the tile comes first, so that the tile starts at LDS
@@ -66,10 +155,8 @@ __global__ void __launch_bounds__(PFT_THREADS)
     // far away that the padding of the rows points to
     double* txyz = reinterpret_cast<double*>(s_dyn);
     const unsigned int tile_len = tile_doubles(cap);
-    tile_tables& T = *reinterpret_cast<tile_tables*>(txyz + tile_len);
+    pft_tables& T = *reinterpret_cast<pft_tables*>(txyz + tile_len);
     // s_home: one entry per home particle and an empty one after the last
-    unsigned int& s_next = *reinterpret_cast<unsigned int*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES - 16);
-    unsigned int& s_word = *reinterpret_cast<unsigned int*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES - 12);
     pft_home_t* s_home = reinterpret_cast<pft_home_t*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES);
     if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
         __builtin_trap(); // the toolchain placed something before the dynamic LDS
@@ -82,33 +169,39 @@ __global__ void __launch_bounds__(PFT_THREADS)
         if (a.d_published && blockIdx.x == 0)
             __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
-        s_word = word;
+        T.word = word;
         }
     const unsigned int np = a.ntypes * a.ntypes;
-    // (the 12-byte home entries end on any multiple of four: the tables of doubles behind them start 16-aligned)
+    // (the 8-byte home entries end on a multiple of eight: pft_home_bytes pads to 16 for the tables of doubles behind them)
     double* s_rcutsq = reinterpret_cast<double*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES + pft_home_bytes(g.cli.w));
     double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
     unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
 
-    // which block of the grid: all of them in launch order, or those inside / outside a window
-    unsigned int vb = tile_xcd_remap(blockIdx.x, gridDim.x);
-    if (a.block_window_mode)
+    // ---- which block of the grid: all of them in launch order, or those inside / outside a window ----
+    const unsigned int nbx = lp.nbx, nby = lp.nby;
+    unsigned int bx, by, bz;
         {
-        const unsigned int nbx = (g.ci.w + TB_X - 1) / TB_X, nby = (g.ci.h + TB_Y - 1) / TB_Y;
-        if (a.block_window_mode == 1)
+        const unsigned int v0 = tile_xcd_remap(blockIdx.x, gridDim.x);
+        if (a.block_window_mode == 0)
+            {
+            const unsigned int q = (unsigned int)(((unsigned long long)v0 * lp.inv_nbx) >> 40); // v0 / nbx
+            bx = v0 - q * nbx;
+            bz = (unsigned int)(((unsigned long long)q * lp.inv_nby) >> 40);
+            by = q - bz * nby;
+            }
+        else if (a.block_window_mode == 1)
             {
             // the launch covers the window only
             const unsigned int wx = a.block_hi[0] - a.block_lo[0] + 1, wy = a.block_hi[1] - a.block_lo[1] + 1;
-            const unsigned int bx = a.block_lo[0] + vb % wx, by = a.block_lo[1] + (vb / wx) % wy, bz = a.block_lo[2] + vb / (wx * wy);
-            vb = (bz * nby + by) * nbx + bx;
+            bx = a.block_lo[0] + v0 % wx, by = a.block_lo[1] + (v0 / wx) % wy, bz = a.block_lo[2] + v0 / (wx * wy);
             }
         else
             {
             // the launch covers the blocks outside the window: six slabs, numbered one after the other
             const unsigned int nbz = (g.ci.d + TB_Z - 1) / TB_Z;
             const unsigned int wy = a.block_hi[1] - a.block_lo[1] + 1, wz = a.block_hi[2] - a.block_lo[2] + 1;
-            unsigned int v = vb, bx, by, bz;
+            unsigned int v = v0;
             const unsigned int nA = nbx * nby * a.block_lo[2], nB = nbx * nby * (nbz - 1 - a.block_hi[2]);
             const unsigned int nC = nbx * a.block_lo[1] * wz, nD = nbx * (nby - 1 - a.block_hi[1]) * wz;
             const unsigned int nE = a.block_lo[0] * wy * wz;
@@ -139,11 +232,71 @@ __global__ void __launch_bounds__(PFT_THREADS)
                 const unsigned int hx = nbx - 1 - a.block_hi[0];
                 bx = a.block_hi[0] + 1 + v % hx, by = a.block_lo[1] + (v / hx) % wy, bz = a.block_lo[2] + v / (hx * wy);
                 }
-            vb = (bz * nby + by) * nbx + bx;
             }
         }
-    int cx0, cy0, cz0;
-    tile_setup(g, a.box, T, cx0, cy0, cz0, vb);
+    const unsigned int vb = (bz * nby + by) * nbx + bx;
+    const int cx0 = TB_X * (int)bx, cy0 = TB_Y * (int)by, cz0 = TB_Z * (int)bz;
+    const int dimx = (int)g.ci.w, dimy = (int)g.ci.h, dimz = (int)g.ci.d;
+
+    // ---- staging, first half: every load of the region is issued before anything is known about the
+    // cells' populations.  Sixteen lanes take one region cell: rx = lane / 16, ry = wave, rz = trip, so a wave
+    // covers a 4x1x4 slab of the region in four trips; slots k16 and k16 + 16 of every cell are fetched
+    // unconditionally (slots past a cell's population hold stale data that is never used), and with them the
+    // row info of the home cells' members.  The cell sizes arrive in the same round trip (wave 0 below):
+    // staging costs one memory latency, not three.
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    const unsigned int rx = lane / 16, k16 = lane % 16;
+    const unsigned int cellNmax = g.cli.w;
+    const pft_axis ax = pft_axis_cell(cx0 - 1 + (int)rx, dimx, a.box.periodic[0]);
+    const pft_axis ay = pft_axis_cell(cy0 - 1 + (int)wave, dimy, a.box.periodic[1]);
+    const bool home_xy = (rx == 1 || rx == 2) && (wave == 1 || wave == 2) && cx0 + (int)rx - 1 < dimx && cy0 + (int)wave - 1 < dimy;
+    pft_pos pA[PFT_TRIPS], pB[PFT_TRIPS];
+    uint2 mA[2], mB[2];
+    pft_axis az[PFT_TRIPS];
+        {
+        // byte offsets fit 32 bits (checked by the launcher): one scalar base plus a 32-bit lane offset per load
+        const unsigned int oA = min(k16, cellNmax - 1u) * 32u, oB = min(k16 + 16u, cellNmax - 1u) * 32u;
+        const char* cpos = reinterpret_cast<const char*>(g.d_cpos);
+        const char* meta = reinterpret_cast<const char*>(g.d_slot_meta);
+#pragma unroll
+        for (int u = 0; u < PFT_TRIPS; u++)
+            {
+            az[u] = pft_axis_cell(cz0 - 1 + u, dimz, a.box.periodic[2]);
+            const bool valid = ax.valid && ay.valid && az[u].valid;
+            const unsigned int base = valid ? (unsigned int)((az[u].c * dimy + ay.c) * dimx + ax.c) * cellNmax * 32u : 0u;
+            pA[u] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oA)));
+            pB[u] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oB)));
+            if ((u == 1 || u == 2) && home_xy)
+                {
+                mA[u - 1] = *reinterpret_cast<const uint2*>(meta + ((base + oA) >> 1));
+                mB[u - 1] = *reinterpret_cast<const uint2*>(meta + ((base + oB) >> 1));
+                }
+            }
+        }
+    // ---- wave 0: populations of the 64 region cells -> prefix sums; home cells -> numbering of the home particles ----
+    if (wave == 0)
+        {
+        const pft_axis tx = pft_axis_cell(cx0 - 1 + (int)(lane % 4), dimx, a.box.periodic[0]);
+        const pft_axis ty = pft_axis_cell(cy0 - 1 + (int)((lane / 4) % 4), dimy, a.box.periodic[1]);
+        const pft_axis tz = pft_axis_cell(cz0 - 1 + (int)(lane / 16), dimz, a.box.periodic[2]);
+        unsigned int size = 0;
+        if (tx.valid && ty.valid && tz.valid)
+            size = min(g.d_cell_size[(tz.c * dimy + ty.c) * dimx + tx.c], cellNmax);
+        const unsigned int incl = tile_wave_scan(size, (int)lane);
+        T.off[lane] = incl - size;
+        if (lane == 63)
+            T.off[64] = incl;
+        // lane hc < 8: the size of home cell hc (region cell (1 + hx, 1 + hy, 1 + hz)) when the grid has it
+        const unsigned int hc = lane % TL_NH;
+        const int hx = hc % TB_X, hy = (hc / TB_X) % TB_Y, hz = hc / (TB_X * TB_Y);
+        const unsigned int hsize = __shfl(size, tile_rc(1 + hx, 1 + hy, 1 + hz), 64);
+        const bool home = lane < (unsigned int)TL_NH && cx0 + hx < dimx && cy0 + hy < dimy && cz0 + hz < dimz;
+        const unsigned int hincl = tile_wave_scan(home ? hsize : 0u, (int)lane);
+        if (lane < (unsigned int)TL_NH)
+            T.hcum[lane + 1] = hincl;
+        if (lane == 0)
+            T.hcum[0] = 0;
+        }
     param_t p0;
     double rcutsq0 = 0.0, ronsq0 = 0.0;
     if (SINGLE_TYPE)
@@ -160,190 +313,87 @@ __global__ void __launch_bounds__(PFT_THREADS)
             s_rcutsq[t] = a.d_rcutsq[t];
             s_ronsq[t] = (SHIFT == 2) ? a.d_ronsq[t] : 0.0;
             }
-    if (threadIdx.x == 0)
-        s_next = 2 * (PFT_THREADS / TPP);
+    // first group of this block's rows (wave-uniform; in flight while the region is staged)
+    const unsigned int grp0 = g.d_block_group[vb];
     __syncthreads();
-    if (a.d_skip_flag && s_word == a.skip_value)
+    if (a.d_skip_flag && T.word == a.skip_value)
         return;
     const unsigned int total = T.off[64];
     if (total > cap || total == 0)
         return;
+    const unsigned int H = T.hcum[TL_NH];
 
-    // ---- home particles: members of the (up to 8) home cells, numbered consecutively ----
-    unsigned int hbeg[TL_NH], hcum[TL_NH + 1];
-    hcum[0] = 0;
+    // ---- staging, second half: place what arrived.  Members of cells away from the periodic faces of the box are
+    // copied as they are; the others go to the periodic image nearest to their region cell, decided per particle
+    // (the integrator wraps a particle that leaves the box, which moves it by a box vector without changing its
+    // cell-list slot): image = rint(centre of the region cell - position) in fractional coordinates
+    // (hoomd/BoxDim.h:260-268, 391-458). ----
 #pragma unroll
-    for (int hc = 0; hc < TL_NH; hc++)
+    for (int u = 0; u < PFT_TRIPS; u++)
         {
-        const int hx = hc % TB_X, hy = (hc / TB_X) % TB_Y, hz = hc / (TB_X * TB_Y);
-        const unsigned int rc = tile_home_rc(hc);
-        const bool home = tile_is_home(g, cx0, cy0, cz0, hx, hy, hz);
-        hbeg[hc] = T.off[rc];
-        hcum[hc + 1] = hcum[hc] + (home ? T.off[rc + 1] - T.off[rc] : 0u);
-        }
-    const unsigned int H = hcum[TL_NH];
-    auto home_local = [&](unsigned int h, unsigned int& rc_home) -> unsigned int
-    {
-        unsigned int lh = 0;
-        rc_home = 0;
-#pragma unroll
-        for (int c = 0; c < TL_NH; c++)
-            if (h >= hcum[c] && h < hcum[c + 1])
-                {
-                lh = hbeg[c] + (h - hcum[c]);
-                rc_home = tile_home_rc(c);
-                }
-        return lh;
-    };
-    const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    if (g.d_cpos && g.d_slot_meta)
+        const unsigned int rc = (unsigned int)tile_rc((int)rx, (int)wave, u);
+        const unsigned int first = T.off[rc], size = T.off[rc + 1] - first;
+        if (__builtin_amdgcn_readfirstlane(__ballot(size != 0) == 0))
+            continue;
+        const bool edge = ax.edge || ay.edge || az[u].edge;
+        // centre of the region cell in fractional coordinates, from its UNWRAPPED grid coordinate
+        const double fcx = ((double)(cx0 - 1 + (int)rx) + 0.5) * lp.inv_dim[0];
+        const double fcy = ((double)(cy0 - 1 + (int)wave) + 0.5) * lp.inv_dim[1];
+        const double fcz = ((double)(cz0 - 1 + u) + 0.5) * lp.inv_dim[2];
+        auto place = [&](const pft_pos& pp, unsigned int k)
         {
-        // ---- fast staging: positions and row info are kept in cell-list slot order, so one round of
-        // loads with every lane busy fills the tile and the home table ----
-        for (unsigned int h = threadIdx.x; h < H; h += PFT_THREADS)
-            {
-            unsigned int rc_home;
-            const unsigned int lh = home_local(h, rc_home);
-            const hmd_uint4 m = g.d_slot_meta[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
-            s_home[h] = pft_home(m.x, m.y, m.z, tile_slot(lh));
-            }
-        // Sixteen lanes take one region cell, so a wave covers four cells per trip and the whole
-        // region in PFT_TRIPS trips, all of whose loads are in flight together.
-        constexpr int PFT_TRIPS = (TL_RC + 4 * PFT_WAVES - 1) / (4 * PFT_WAVES);
-        const double reach_sq = tile_reach_sq(a.box);
-        const unsigned int k16 = lane % 16;
-        double4 p[PFT_TRIPS];
-        unsigned int rcs[PFT_TRIPS], size[PFT_TRIPS];
-#pragma unroll
-        for (int u = 0; u < PFT_TRIPS; u++)
-            {
-            rcs[u] = (u * PFT_WAVES + wave) * 4 + lane / 16;
-            size[u] = rcs[u] < (unsigned int)TL_RC ? T.off[rcs[u] + 1] - T.off[rcs[u]] : 0u;
-            rcs[u] = min(rcs[u], (unsigned int)TL_RC - 1);
-            const unsigned int slot = size[u] ? (unsigned int)T.cell[rcs[u]] * g.cli.w + min(k16, size[u] - 1) : 0u;
-            p[u] = hmd_ld4(g.d_cpos + slot);
-            }
-#pragma unroll
-        for (int u = 0; u < PFT_TRIPS; u++)
-            {
-            const unsigned int rc = rcs[u];
-            const tile_cell_image ci = tile_cell_setup(a.box, T, rc);
-            const unsigned int first = T.off[rc];
-            const hmd_scalar4* cell_pos = g.d_cpos + (size[u] ? (unsigned int)T.cell[rc] * g.cli.w : 0u);
-            double4 pp = p[u];
-            for (unsigned int k = k16; k < size[u]; k += 16)
+            double x = pp.x, y = pp.y, z = pp.z;
+            if (edge)
                 {
-                if (k >= 16)
-                    pp = hmd_ld4(cell_pos + k);
-                double x = pp.x, y = pp.y, z = pp.z;
-                const double dx = x - ci.qx, dy = y - ci.qy, dz = z - ci.qz;
-                if (dx * dx + dy * dy + dz * dz < reach_sq)
-                    {
-                    x += ci.sx;
-                    y += ci.sy;
-                    z += ci.sz;
-                    }
-                else
-                    tile_place(a.box, T, rc, x, y, z);
-                const unsigned int v = tile_slot(first + k);
-                txyz[v] = x;
-                txyz[v + 32] = y;
-                txyz[v + 64] = z;
-                if (!SINGLE_TYPE)
-                    ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
+                const double fx = ((x - a.box.lo[0]) - ((a.box.xz - a.box.yz * a.box.xy) * z + a.box.xy * y)) * a.box.Linv[0];
+                const double fy = ((y - a.box.lo[1]) - a.box.yz * z) * a.box.Linv[1];
+                const double fz = (z - a.box.lo[2]) * a.box.Linv[2];
+                const double ix = a.box.periodic[0] ? rint(fcx - fx) : 0.0;
+                const double iy = a.box.periodic[1] ? rint(fcy - fy) : 0.0;
+                const double iz = a.box.periodic[2] ? rint(fcz - fz) : 0.0;
+                tile_shift(a.box, ix, iy, iz, x, y, z);
                 }
-            }
-        }
-    else
-        {
-        // ---- stage the region (one wave per region cell, eight cells in flight) and the home table.
-        // Loads are issued in two dependent rounds only: member indices, then positions / row info. ----
-        unsigned int my_h = threadIdx.x, my_idx = 0, my_lh = 0;
-        if (my_h < H)
+            const unsigned int v = tile_slot(first + k);
+            txyz[v] = x;
+            txyz[v + 32] = y;
+            txyz[v + 64] = z;
+            if (!SINGLE_TYPE)
+                ttype[v] = (unsigned char)pp.t;
+        };
+        if (k16 < size)
+            place(pA[u], k16);
+        if (k16 + 16u < size)
+            place(pB[u], k16 + 16u);
+        // members of a home cell of this block get their entry of the home table
+        const bool home_cell = (u == 1 || u == 2) && home_xy && cz0 + u - 1 < dimz;
+        unsigned int hfirst = 0;
+        if (u == 1 || u == 2)
             {
-            unsigned int rc_home;
-            my_lh = home_local(my_h, rc_home);
-            my_idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (my_lh - T.off[rc_home])];
+            if (home_cell)
+                hfirst = T.hcum[((u - 1) * TB_Y + (wave - 1)) * TB_X + (rx - 1)];
+            if (home_cell && k16 < size)
+                s_home[hfirst + k16] = pft_home(mA[u - 1].x, mA[u - 1].y, tile_slot(first + k16));
+            if (home_cell && k16 + 16u < size)
+                s_home[hfirst + k16 + 16u] = pft_home(mB[u - 1].x, mB[u - 1].y, tile_slot(first + k16 + 16u));
             }
-    #pragma unroll
-        for (int round = 0; round < 2; round++)
+        // cells with more than 32 members (uncommon): the rest, one dependent load per trip
+        if (__builtin_amdgcn_readfirstlane(__ballot(size > 32u) != 0))
             {
-            const unsigned int rc0 = wave * PFT_CELLS + round * PFT_BATCH;
-            unsigned int idx[PFT_BATCH];
-            bool on[PFT_BATCH];
-    #pragma unroll
-            for (int q = 0; q < PFT_BATCH; q++)
+            const unsigned int base = (unsigned int)((az[u].c * dimy + ay.c) * dimx + ax.c) * cellNmax;
+            for (unsigned int k = k16 + 32u; k < size; k += 16u)
                 {
-                const unsigned int rc = rc0 + q;
-                on[q] = rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC) && lane < T.off[rc + 1] - T.off[rc];
-                idx[q] = on[q] ? g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + lane] : 0u;
-                }
-            double4 p[PFT_BATCH];
-    #pragma unroll
-            for (int q = 0; q < PFT_BATCH; q++)
-                p[q] = hmd_ld4(a.d_pos + idx[q]);
-            if (round == 0 && my_h < H)
-                {
-                unsigned int nn = 0, row = 0;
-                if (my_idx < a.N)
+                place(pft_ld_pos<!SINGLE_TYPE>(g.d_cpos + base + k), k);
+                if (home_cell)
                     {
-                    nn = a.d_n_neigh[my_idx];
-                    row = (unsigned int)(a.d_head_list[my_idx] / 4);
-                    }
-                s_home[my_h] = pft_home(my_idx, nn, row, tile_slot(my_lh));
-                }
-    #pragma unroll
-            for (int q = 0; q < PFT_BATCH; q++)
-                {
-                const unsigned int rc = rc0 + q;
-                if (on[q])
-                    {
-                    const unsigned int v = tile_slot(T.off[rc] + lane);
-                    double x = p[q].x, y = p[q].y, z = p[q].z;
-                    tile_place(a.box, T, rc, x, y, z);
-                    txyz[v] = x;
-                    txyz[v + 32] = y;
-                    txyz[v + 64] = z;
-                    if (!SINGLE_TYPE)
-                        ttype[v] = (unsigned char)hmd_double_as_uint(p[q].w);
+                    const uint2 m = *reinterpret_cast<const uint2*>(g.d_slot_meta + base + k);
+                    s_home[hfirst + k] = pft_home(m.x, m.y, tile_slot(first + k));
                     }
                 }
-            }
-        // the uncommon leftovers: cells with more than 64 members, blocks with more than 256 home particles
-        for (unsigned int rc = wave * PFT_CELLS; rc < min((wave + 1) * PFT_CELLS, (unsigned int)TL_RC); rc++)
-            {
-            const unsigned int size = T.off[rc + 1] - T.off[rc];
-            for (unsigned int k = lane + 64; k < size; k += 64)
-                {
-                const unsigned int j = g.d_cell_idx[(unsigned int)T.cell[rc] * g.cli.w + k];
-                const double4 pp = hmd_ld4(a.d_pos + j);
-                const unsigned int v = tile_slot(T.off[rc] + k);
-                double x = pp.x, y = pp.y, z = pp.z;
-                tile_place(a.box, T, rc, x, y, z);
-                txyz[v] = x;
-                txyz[v + 32] = y;
-                txyz[v + 64] = z;
-                if (!SINGLE_TYPE)
-                    ttype[v] = (unsigned char)hmd_double_as_uint(pp.w);
-                }
-            }
-        for (unsigned int h = threadIdx.x + PFT_THREADS; h < H; h += PFT_THREADS)
-            {
-            unsigned int rc_home;
-            const unsigned int lh = home_local(h, rc_home);
-            const unsigned int idx = g.d_cell_idx[(unsigned int)T.cell[rc_home] * g.cli.w + (lh - T.off[rc_home])];
-            unsigned int nn = 0, row = 0;
-            if (idx < a.N)
-                {
-                nn = a.d_n_neigh[idx];
-                row = (unsigned int)(a.d_head_list[idx] / 4);
-                }
-            s_home[h] = pft_home(idx, nn, row, tile_slot(lh));
             }
         }
     if (threadIdx.x == 0)
         {
-        s_home[H] = pft_home_t {0u, 0u, 0u};
+        s_home[H] = pft_home_t {0u, 0u};
         const unsigned int v = tile_slot(total);
         txyz[v] = 1e30;
         txyz[v + 32] = 1e30;
@@ -353,60 +403,63 @@ __global__ void __launch_bounds__(PFT_THREADS)
         }
     __syncthreads();
 
-    // ---- forces: groups of TPP lanes take home particles from a shared counter.  A row is fetched
-    // whole (PFT_CH chunks of four entries per lane) two home particles ahead of its use: rows stream
-    // from HBM exactly once, so what bounds this phase is the number of bytes in flight. ----
-    constexpr int PFT_CH = 4;
+    // ---- forces: a wave takes the block's groups of sixteen rows in turn (wave w: groups w, w + 4, ...).  The
+    // first PFT_PRE pieces of every row of the next group are fetched while the present one is computed: rows
+    // stream from HBM exactly once, so what bounds this phase is the number of bytes in flight. ----
 #ifdef HMD_PFT_STAGE_ONLY
     if (total != 0xdeadbeefu)
         return;
 #endif
-    const unsigned int sub = threadIdx.x % TPP;
-    const unsigned int leader = (lane / TPP) * TPP;
-    const unsigned char* rows = reinterpret_cast<const unsigned char*>(d_tile_nlist);
-    // Rows are padded to a multiple of four entries with the dummy's slot.  Chunks past the end of a
-    // row read the following rows or the 512-byte slack after the last one; never used.
+    const unsigned int s4 = lane % PFT_T, gl = lane / PFT_T;
+    const unsigned int ngroups = (H + TL_GROUP - 1) / TL_GROUP;
+    const unsigned int P = g.row_pieces;
+    // piece p of group j of this block: 64 uint2 (four entries each) at rows[(j * P + p) * 64], lane order
+    const uint2* rows = reinterpret_cast<const uint2*>(d_tile_nlist) + (size_t)grp0 * P * 64 + lane;
     const unsigned int three = 3u;
-    auto fetch = [&](const pft_home_t& e, uint2 (&c)[PFT_CH])
+    auto fetch = [&](unsigned int grp, uint2 (&c)[PFT_PRE])
     {
-        const uint2* row = reinterpret_cast<const uint2*>(rows) + e.row;
+        const uint2* rp = rows + (size_t)grp * P * 64;
 #pragma unroll
-        for (int q = 0; q < PFT_CH; q++)
-            c[q] = row[sub + TPP * q];
+        for (int q = 0; q < PFT_PRE; q++)
+            c[q] = rp[min((unsigned int)q, P - 1u) * 64u]; // rows with room for fewer pieces: read the last one again
     };
-    auto grab = [&](unsigned int& h, pft_home_t& e, uint2 (&c)[PFT_CH])
+    auto process = [&](unsigned int grp, const uint2 (&cur)[PFT_PRE])
     {
-        unsigned int nh = 0;
-        if (sub == 0)
-            nh = atomicAdd(&s_next, 1u);
-        h = __shfl(nh, leader, 64);
-        e = s_home[min(h, H)]; // s_home[H] is an empty entry
-        fetch(e, c);
-    };
-    auto process = [&](const pft_home_t& e, const uint2 (&cur)[PFT_CH])
-    {
+        const unsigned int h = grp * TL_GROUP + gl;
+        const pft_home_t e = s_home[min(h, H)]; // s_home[H] is an empty entry
         const unsigned int lh = e.nn_lh >> 16;
+        const unsigned int nn = min(e.nn_lh & 0xffffu, P * TL_PIECE);
         pf_accum acc;
-        const unsigned int nn = e.nn_lh & 0xffffu;
         const double xi = txyz[lh], yi = txyz[lh + 32], zi = txyz[lh + 64];
         const unsigned int ti = SINGLE_TYPE ? 0u : (unsigned int)ttype[lh];
-        auto chunk = [&](uint2 w)
+        // coordinates of the four neighbors of one row chunk, read from the tile
+        struct quad
+            {
+            double x[4], y[4], z[4];
+            unsigned int j[4];
+            };
+        auto read_quad = [&](uint2 w, quad& c)
         {
-#ifdef HMD_PFT_SKELETON
-            acc.fx += (double)(w.x ^ w.y);
-            return;
-#endif
-            const unsigned int j[4] = {pft_slot_bytes<0>(w.x, three), pft_slot_bytes<1>(w.x, three), pft_slot_bytes<0>(w.y, three), pft_slot_bytes<1>(w.y, three)};
-            double xj[4], yj[4], zj[4];
+            c.j[0] = pft_slot_bytes<0>(w.x, three);
+            c.j[1] = pft_slot_bytes<1>(w.x, three);
+            c.j[2] = pft_slot_bytes<0>(w.y, three);
+            c.j[3] = pft_slot_bytes<1>(w.y, three);
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 {
                 // three 8-byte reads: paired 16-byte LDS reads run at half the rate (volatile keeps them apart)
-                pft_lds_double* c = (pft_lds_double*)(size_t)j[m];
-                xj[m] = c[0];
-                yj[m] = *(volatile pft_lds_double*)(c + 32);
-                zj[m] = *(volatile pft_lds_double*)(c + 64);
+                pft_lds_double* t = (pft_lds_double*)(size_t)c.j[m];
+                c.x[m] = t[0];
+                c.y[m] = *(volatile pft_lds_double*)(t + 32);
+                c.z[m] = *(volatile pft_lds_double*)(t + 64);
                 }
+        };
+        auto pairs = [&](const quad& c)
+        {
+#ifdef HMD_PFT_SKELETON
+            acc.fx += c.x[0] + c.y[1] + c.z[2] + c.x[3];
+            return;
+#endif
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 {
@@ -420,47 +473,88 @@ __global__ void __launch_bounds__(PFT_THREADS)
                     }
                 else
                     {
-                    const unsigned int tp = (unsigned int)ttype[j[m] >> 3] * a.ntypes + ti;
+                    const unsigned int tp = (unsigned int)ttype[c.j[m] >> 3] * a.ntypes + ti;
                     rcutsq = s_rcutsq[tp];
                     if (SHIFT == 2)
                         ronsq = s_ronsq[tp];
                     prm = s_params + tp;
                     }
-                pf_pair<Ev, SHIFT, VIRIAL>(acc, xi - xj[m], yi - yj[m], zi - zj[m], rcutsq, ronsq, *prm, 0.0, 0.0);
+                pf_pair<Ev, SHIFT, VIRIAL>(acc, xi - c.x[m], yi - c.y[m], zi - c.z[m], rcutsq, ronsq, *prm, 0.0, 0.0);
                 }
         };
+        // Rows are padded to a multiple of four entries with the dummy's slot; pieces past the end of a row hold
+        // whatever was there: their lanes are switched off.  The tile reads of the next chunk are issued before the
+        // arithmetic of the present one, so a wave does not sit idle through the LDS latency at every chunk.
+        // (only where the registers allow it without spilling: the plain potential without virials)
+#ifdef HMD_PFT_NO_PIPE
+        constexpr bool PIPELINED = false;
+#else
+        constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL);
+#endif
+        quad qa;
+        if (PIPELINED)
+            {
+            quad qb;
+            bool on = 4u * s4 < nn;
+            if (on)
+                read_quad(cur[0], qa);
 #pragma unroll
-        for (int q = 0; q < PFT_CH; q++)
-            if (4 * (sub + TPP * q) < nn)
-                chunk(cur[q]);
-        // rows longer than PFT_CH * 4 * TPP entries
-        for (unsigned int k = 4 * (sub + TPP * PFT_CH); k < nn; k += 4 * TPP)
-            chunk((reinterpret_cast<const uint2*>(rows) + e.row)[k / 4]);
-        pf_finish<VIRIAL, TPP>(acc, a, e.idx, e.idx < a.N && sub == 0);
+            for (int q = 0; q < PFT_PRE; q++)
+                {
+                quad& now = (q & 1) ? qb : qa;
+                quad& next = (q & 1) ? qa : qb;
+                const bool on_next = q + 1 < PFT_PRE && (unsigned int)(TL_PIECE * (q + 1)) + 4u * s4 < nn;
+                if (on_next)
+                    read_quad(cur[q + 1], next);
+                if (on)
+                    pairs(now);
+                on = on_next;
+                }
+            }
+        else
+            {
+#pragma unroll
+            for (int q = 0; q < PFT_PRE; q++)
+                if ((unsigned int)(TL_PIECE * q) + 4u * s4 < nn)
+                    {
+                    read_quad(cur[q], qa);
+                    pairs(qa);
+                    }
+            }
+        // rows longer than PFT_PRE pieces
+        if (__any((unsigned int)(TL_PIECE * PFT_PRE) < nn))
+            {
+            const uint2* rp = rows + (size_t)grp * P * 64;
+            for (unsigned int q = PFT_PRE; q < P; q++)
+                {
+                const bool more = TL_PIECE * q + 4u * s4 < nn;
+                if (!__any(more))
+                    break;
+                if (more)
+                    {
+                    read_quad(rp[q * 64u], qa);
+                    pairs(qa);
+                    }
+                }
+            }
+        pf_finish<VIRIAL, PFT_T>(acc, a, e.idx, h < H && e.idx < a.N && s4 == 0);
     };
-    // Three row buffers in rotation: while one home particle is computed, the rows of the next two
-    // are on their way.  The counter hands out increasing numbers, so a group is done at the first
-    // number past the end.
-    constexpr unsigned int groups = PFT_THREADS / TPP;
-    unsigned int h0 = threadIdx.x / TPP, h1 = h0 + groups, h2;
-    pft_home_t e0 = s_home[min(h0, H)], e1 = s_home[min(h1, H)], e2;
-    uint2 b0[PFT_CH], b1[PFT_CH], b2[PFT_CH];
-    fetch(e0, b0);
-    fetch(e1, b1);
-    for (;;)
+    uint2 b0[PFT_PRE], b1[PFT_PRE];
+    unsigned int grp = wave;
+    if (grp < ngroups)
+        fetch(grp, b0);
+    while (grp < ngroups)
         {
-        if (h0 >= H)
+        if (grp + PFT_WAVES < ngroups)
+            fetch(grp + PFT_WAVES, b1);
+        process(grp, b0);
+        grp += PFT_WAVES;
+        if (grp >= ngroups)
             break;
-        grab(h2, e2, b2);
-        process(e0, b0);
-        if (h1 >= H)
-            break;
-        grab(h0, e0, b0);
-        process(e1, b1);
-        if (h2 >= H)
-            break;
-        grab(h1, e1, b1);
-        process(e2, b2);
+        if (grp + PFT_WAVES < ngroups)
+            fetch(grp + PFT_WAVES, b0);
+        process(grp, b1);
+        grp += PFT_WAVES;
         }
     }
 
@@ -474,7 +568,7 @@ template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned
 
 template<class Ev, unsigned int SHIFT, bool VIRIAL>
 int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsigned short* d_tile_nlist,
-                const typename Ev::param_type* d_params, unsigned int tpp, hipStream_t s)
+                const typename Ev::param_type* d_params, hipStream_t s)
     {
     const size_t lds = pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w);
     unsigned int nblocks = tile_num_blocks(g.ci);
@@ -486,27 +580,24 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
             return HMD_OK; // the window is the whole grid: nothing outside it
         }
     const dim3 grid(nblocks), block(PFT_THREADS);
-#define HMD_PFT_LAUNCH(TPPV)                                                                                               \
-    if (a.ntypes == 1)                                                                                                     \
-        {                                                                                                                  \
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, true>, lds);                                   \
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params);  \
-        }                                                                                                                  \
-    else                                                                                                                   \
-        {                                                                                                                  \
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, false>, lds);                                  \
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, TPPV, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params); \
-        }
-    switch (tpp)
+    pft_launch_t lp;
+    lp.nbx = (g.ci.w + TB_X - 1) / TB_X;
+    lp.nby = (g.ci.h + TB_Y - 1) / TB_Y;
+    lp.inv_nbx = ((1ull << 40) + lp.nbx - 1) / lp.nbx;
+    lp.inv_nby = ((1ull << 40) + lp.nby - 1) / lp.nby;
+    lp.inv_dim[0] = 1.0 / (double)g.ci.w;
+    lp.inv_dim[1] = 1.0 / (double)g.ci.h;
+    lp.inv_dim[2] = 1.0 / (double)g.ci.d;
+    if (a.ntypes == 1)
         {
-    case 4:
-        HMD_PFT_LAUNCH(4) break;
-    case 16:
-        HMD_PFT_LAUNCH(16) break;
-    default:
-        HMD_PFT_LAUNCH(8) break;
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
         }
-#undef HMD_PFT_LAUNCH
+    else
+        {
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        }
     return hmd_launch_status();
     }
 
@@ -518,12 +609,16 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
                 "pair forces (tiles): args, geom, d_tile_nlist and d_params are required");
     const hmd_pair_args_t& a = *args;
     const hmd_tile_geom_t& g = *geom;
-    HMD_REQUIRE(a.d_force && a.d_pos && a.d_n_neigh && a.d_head_list && a.d_rcutsq, HMD_ERR_INVALID_ARGUMENT,
-                "pair forces (tiles): force, pos, n_neigh, head_list and rcutsq are required");
+    HMD_REQUIRE(a.d_force && a.d_pos && a.d_n_neigh && a.d_rcutsq, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): force, pos, n_neigh and rcutsq are required");
+    HMD_REQUIRE(g.d_block_group && g.row_pieces >= 1, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): geom.d_block_group and geom.row_pieces are required");
     HMD_REQUIRE(g.d_cell_size && g.d_cell_idx, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): the cell arrays are required");
+    HMD_REQUIRE((size_t)g.cli.w * g.cli.h * 32 <= 0xffffffffull && tile_num_blocks(g.ci) < (1u << 24) && g.ci.w < 65536 && g.ci.h < 65536,
+                HMD_ERR_TOO_LARGE, "pair forces (tiles): the cell list exceeds 2^27 slots or the grid 2^24 blocks");
+    HMD_REQUIRE(g.d_cpos && g.d_slot_meta, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): geom.d_cpos (hmd_tile_refresh) and geom.d_slot_meta (hmd_compute_nlist_tiles) are required");
     HMD_REQUIRE((reinterpret_cast<uintptr_t>(d_tile_nlist) & 7) == 0, HMD_ERR_INVALID_ARGUMENT,
                 "pair forces (tiles): d_tile_nlist must be 8-byte aligned");
-    HMD_REQUIRE(a.size_neigh_list / 4 <= 0xffffffffull, HMD_ERR_TOO_LARGE, "pair forces (tiles): more than 2^34 row entries");
     HMD_REQUIRE(a.shift_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): shift_mode must be 0, 1 or 2");
     HMD_REQUIRE(a.shift_mode != 2 || a.d_ronsq, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): xplor needs d_ronsq");
     HMD_REQUIRE(!a.compute_virial || a.d_virial, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): compute_virial needs d_virial");
@@ -542,8 +637,8 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
             HMD_REQUIRE(a.block_lo[d] <= a.block_hi[d] && a.block_hi[d] < nb[d], HMD_ERR_INVALID_ARGUMENT,
                         "pair forces (tiles): the block window must lie inside the grid of blocks and hold at least one block");
         }
-    const unsigned int tpp = a.threads_per_particle ? a.threads_per_particle : 8;
-    HMD_REQUIRE(tpp == 4 || tpp == 8 || tpp == 16, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): threads_per_particle must be 4, 8 or 16");
+    HMD_REQUIRE(a.threads_per_particle == 0 || a.threads_per_particle == PFT_T, HMD_ERR_INVALID_ARGUMENT,
+                "pair forces (tiles): threads_per_particle must be 0 or 4");
     if (a.N == 0)
         return HMD_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -551,11 +646,11 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
     switch (a.shift_mode)
         {
     case 0:
-        return vir ? pft_launch2<Ev, 0, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 0, false>(a, g, d_tile_nlist, d_params, tpp, s);
+        return vir ? pft_launch2<Ev, 0, true>(a, g, d_tile_nlist, d_params, s) : pft_launch2<Ev, 0, false>(a, g, d_tile_nlist, d_params, s);
     case 1:
-        return vir ? pft_launch2<Ev, 1, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 1, false>(a, g, d_tile_nlist, d_params, tpp, s);
+        return vir ? pft_launch2<Ev, 1, true>(a, g, d_tile_nlist, d_params, s) : pft_launch2<Ev, 1, false>(a, g, d_tile_nlist, d_params, s);
     default:
-        return vir ? pft_launch2<Ev, 2, true>(a, g, d_tile_nlist, d_params, tpp, s) : pft_launch2<Ev, 2, false>(a, g, d_tile_nlist, d_params, tpp, s);
+        return vir ? pft_launch2<Ev, 2, true>(a, g, d_tile_nlist, d_params, s) : pft_launch2<Ev, 2, false>(a, g, d_tile_nlist, d_params, s);
         }
     }
     } // namespace hmd

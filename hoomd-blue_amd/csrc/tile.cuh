@@ -46,6 +46,22 @@ __host__ __device__ constexpr unsigned int tile_doubles(unsigned int cap)
     return (cap / 32u + 1u) * 96u;
     }
 
+// Row storage: rows of TL_GROUP home particles are interleaved in pieces of TL_PIECE entries (32 bytes), so the
+// TL_GROUP * TL_PIECE / 4 = 64 lanes of a wave -- four per home particle, four entries per lane -- read 512
+// consecutive bytes per trip.  Entry k of the member `g` of a group sits at this 16-bit offset from the group's
+// first entry when rows have room for P pieces.
+constexpr unsigned int TL_GROUP = 16, TL_PIECE = 16;
+__host__ __device__ constexpr size_t tile_row_entry(unsigned int g, unsigned int k)
+    {
+    return ((size_t)(k / TL_PIECE) * TL_GROUP + g) * TL_PIECE + k % TL_PIECE;
+    }
+__host__ __device__ constexpr size_t tile_group_entries(unsigned int P)
+    {
+    return (size_t)P * TL_GROUP * TL_PIECE;
+    }
+// pieces past the last group that the force kernel's prefetch may read
+constexpr unsigned int TL_SLACK_GROUPS = 2;
+
 // region cell number of region coordinates, and of home cell hc = (hz*TB_Y + hy)*TB_X + hx
 __host__ __device__ constexpr int tile_rc(int rx, int ry, int rz)
     {

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libhoomd_amd.so")
+# HOOMD_AMD_LIB: an experimental build of the library (make -C csrc variant ...), for kernel timing scripts only
+LIB_PATH = os.environ.get("HOOMD_AMD_LIB") or os.path.join(_PKG_ROOT, "libhoomd_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -225,14 +226,14 @@ class FusedStepArgs(C.Structure):
 
 class TileGeom(C.Structure):
     _fields_ = [("d_cell_size", vp), ("d_cell_idx", vp), ("ci", Index3D), ("cli", Index2D), ("capacity", u32), ("d_cpos", vp),
-                ("d_slot_meta", vp)]
+                ("d_slot_meta", vp), ("d_block_group", vp), ("row_pieces", u32)]
 
 
 class NlistTilesArgs(C.Structure):
     _fields_ = [("geom", TileGeom), ("d_cell_xyzf", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp), ("cadji", Index2D),
                 ("d_tile_nlist", vp), ("d_slot_meta", vp), ("d_slot_of", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp),
                 ("d_Nmax", vp), ("d_head_list", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
-                ("ntypes", u32), ("d_tile_overflow", vp)]
+                ("ntypes", u32), ("d_tile_overflow", vp), ("tile_nlist_entries", C.c_size_t)]
 
 
 class TilesToRowsArgs(C.Structure):
@@ -286,6 +287,7 @@ _SIGNATURES = {
     "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
     "hmd_nve_step_two_one_check": (C.c_int, [C.POINTER(FusedStepArgs), vp]),
     "hmd_nlist_tiles_supported": (C.c_int, [C.POINTER(Index3D), C.POINTER(Box), u32, u32, C.POINTER(u32)]),
+    "hmd_nlist_tiles_storage_entries": (C.c_size_t, [C.POINTER(Index3D), u32, u32]),
     "hmd_tile_slots": (C.c_int, [C.POINTER(TileGeom), vp, vp]),
     "hmd_tile_refresh": (C.c_int, [vp, vp, vp, u32, vp]),
     "hmd_compute_nlist_tiles": (C.c_int, [C.POINTER(NlistTilesArgs), vp]),

@@ -203,9 +203,16 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
     last_pos = torch.zeros((max(N, 1), 4), dtype=torch.float64, device=dev)
     overflow = torch.zeros(2, dtype=torch.int32, device=dev)
     n_builds = 0
+    n_members = int(pos.shape[0])  # owned + ghost particles in the cell list
+    nblocks = ((cl["dim"][0] + 1) // 2) * ((cl["dim"][1] + 1) // 2) * ((cl["dim"][2] + 1) // 2)
+    block_group = torch.zeros(nblocks + 1, dtype=torch.int32, device=dev)
+    geom.d_block_group = ptr(block_group)
     while True:
         head, total = build_head_list(pos, N, Nmax_t)
-        tiles = torch.zeros(max(total, 4) + 256, dtype=torch.int16, device=dev)  # 512 bytes of slack for the force kernel's prefetch
+        geom.row_pieces = (int(Nmax_t.max().item()) + 15) // 16
+        entries = _abi.lib.hmd_nlist_tiles_storage_entries(C.byref(geom.ci), n_members, geom.row_pieces)
+        tiles = torch.zeros(entries, dtype=torch.int16, device=dev)
+        overflow.zero_()
         n_neigh = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
         cond = torch.zeros(nt, dtype=torch.int32, device=dev)
         a = _abi.NlistTilesArgs()
@@ -217,6 +224,7 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
         a.d_tile_nlist, a.d_n_neigh, a.d_last_updated_pos, a.d_conditions = ptr(tiles), ptr(n_neigh), ptr(last_pos), ptr(cond)
         a.d_Nmax, a.d_head_list, a.d_pos, a.N, a.box = ptr(Nmax_t), ptr(head), ptr(pos), N, box
         a.d_r_cut, a.r_buff, a.ntypes, a.d_tile_overflow = ptr(r_cut_t), float(r_buff), nt, ptr(overflow)
+        a.tile_nlist_entries = entries
         check(_abi.lib.hmd_compute_nlist_tiles(C.byref(a), _stream(pos)), "hmd_compute_nlist_tiles")
         n_builds += 1
         if int(overflow[0].item()):
@@ -233,12 +241,12 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
         check(_abi.lib.hmd_tile_slots(C.byref(geom), ptr(slot_of), _stream(pos)), "hmd_tile_slots")
         # geom points into the cell list's tensors: keep them alive with the result
         return dict(slot_meta=slot_meta, slot_of=slot_of, tiles=tiles, n_neigh=n_neigh, head=head, last_pos=last_pos, Nmax=Nmax_t, n_builds=n_builds, geom=geom, args=a,
-                    cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow)
+                    cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow, block_group=block_group, nlist_size=total)
 
 
 def tiles_to_rows(tl, N, box):
     dev = tl["tiles"].device
-    nlist = torch.full((tl["tiles"].numel(),), -1, dtype=torch.int32, device=dev)
+    nlist = torch.full((max(tl["nlist_size"], 4),), -1, dtype=torch.int32, device=dev)
     a = _abi.TilesToRowsArgs()
     a.geom = tl["geom"]
     a.d_tile_nlist, a.d_n_neigh, a.d_head_list, a.d_nlist, a.N, a.box = ptr(tl["tiles"]), ptr(tl["n_neigh"]), ptr(tl["head"]), ptr(nlist), N, box
@@ -280,10 +288,10 @@ def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, sh
     a.shift_mode, a.compute_virial, a.threads_per_particle = shift_mode, int(compute_virial), tpp
     fn = {"lj": _abi.lib.hmd_compute_pair_forces_lj_tiles, "example": _abi.lib.hmd_compute_pair_forces_example_tiles}[evaluator]
     geom = _abi.TileGeom.from_buffer_copy(tl["geom"])
-    cpos = None
+    # the kernel stages the region from the slot-ordered copy of the positions and the per-slot row info
+    cpos = tile_refresh(pos, tl)
+    geom.d_cpos, geom.d_slot_meta = ptr(cpos), ptr(tl["slot_meta"])
     if fast:
-        cpos = tile_refresh(pos, tl)
-        geom.d_cpos, geom.d_slot_meta = ptr(cpos), ptr(tl["slot_meta"])
         geom.capacity = max(int(tl["overflow"][1].item()), 1)  # the largest region the build saw: the exact LDS need
     check(fn(C.byref(a), C.byref(geom), ptr(tl["tiles"]), ptr(prm), _stream(pos)), "hmd_compute_pair_forces_%s_tiles" % evaluator)
     return force, virial

@@ -239,8 +239,8 @@ bool PotentialPairGPU<Ev>::launchKernel(const unsigned int* d_skip_flag, unsigne
     a.shift_mode = (unsigned int)m_shift_mode;
     a.compute_virial = m_pdata->getFlag(pressure_tensor) ? 1u : 0u;
     a.threads_per_particle = m_tpp;
-    if (tiles && m_tpp != 4 && m_tpp != 8 && m_tpp != 16)
-        a.threads_per_particle = 0; // the tile kernel is built for 4, 8 and 16 lanes per particle
+    if (tiles)
+        a.threads_per_particle = 0; // the tile kernel always puts four lanes on a home particle (its row layout is built for that)
     if (!tiles && m_tpp == 0)
         {
         // the reference tunes this at run time (hoomd/md/PotentialPairGPU.h:120-145); here: rows of at most 32

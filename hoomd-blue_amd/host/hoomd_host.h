@@ -1118,6 +1118,8 @@ class NeighborListGPUBinned : public Compute
     bool m_tiles_enabled = true, m_tiles_active = false, m_rows_valid = true, m_tiles_overflowed = false;
     unsigned int m_tile_capacity = 0;
     DeviceArray<unsigned short> m_tile_nlist;
+    DeviceArray<unsigned int> m_block_group; // first group of rows of every block of 2x2x2 cells
+    unsigned int m_row_pieces = 1;           // 16-entry pieces every tile row has room for
     DeviceArray<unsigned int> m_slot_of;   // particle index -> cell-list slot
     DeviceArray<Scalar4> m_cpos;           // positions in slot order, refreshed before each force launch
     DeviceArray<hmd_uint4> m_slot_meta;    // per slot: particle index, n_neigh, row offset / 4
@@ -1698,7 +1700,8 @@ struct KernelTimer
         {
         m_filter = name;
         }
-    //! samples shorter than this are booked under "<name>_skipped" (launches that were predicated off)
+    //! samples shorter than this are booked under "<name>_skipped" (launches that were predicated off); a negative
+    //! value is relative: that fraction of the median sample of the same name
     void setMinMs(double ms)
         {
         m_min_ms = ms;

@@ -462,8 +462,17 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
     unsigned int capacity = 0;
     if (tilesUsable(capacity))
         {
-        if (m_tile_nlist.size() < m_nlist.size() + 256)
-            m_tile_nlist.resize(m_nlist.size() + 256, false);
+        // rows of the tile path: room for the longest row any type may have, in pieces of 16 entries, for every
+        // member of the cell list (owned and ghost) plus one partly filled group per block
+        const hmd_index3d_t ci = m_cl->getCellIndexer();
+        const unsigned int nmax_all = *std::max_element(m_Nmax.begin(), m_Nmax.end());
+        m_row_pieces = (nmax_all + 15) / 16;
+        const size_t entries = hmd_nlist_tiles_storage_entries(&ci, m_pdata->getN() + m_pdata->getNGhosts(), m_row_pieces);
+        if (m_tile_nlist.size() < entries)
+            m_tile_nlist.resize(entries + entries / 8, false);
+        const size_t nblocks = (size_t)((ci.w + 1) / 2) * ((ci.h + 1) / 2) * ((ci.d + 1) / 2);
+        if (m_block_group.size() < nblocks + 1)
+            m_block_group.resize(nblocks + 1, false);
         const hmd_index2d_t cli = m_cl->getCellListIndexer();
         const size_t nslots = (size_t)cli.w * cli.h;
         if (m_cpos.size() < nslots)
@@ -496,6 +505,7 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         a.r_buff = m_r_buff;
         a.ntypes = m_pdata->getNTypes();
         a.d_tile_overflow = m_conditions.get() + a.ntypes;
+        a.tile_nlist_entries = m_tile_nlist.size();
         hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
         abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
         m_cpos_tstep = timestep; // current for every particle, ghosts included
@@ -544,6 +554,8 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
     g.capacity = m_tile_capacity;
     g.d_cpos = m_cpos.get();
     g.d_slot_meta = m_slot_meta.get();
+    g.d_block_group = m_block_group.get();
+    g.row_pieces = m_row_pieces;
     return g;
     }
 

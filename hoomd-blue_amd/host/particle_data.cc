@@ -435,13 +435,36 @@ void KernelTimer::end(const char* name)
 std::vector<std::tuple<std::string, uint64_t, double>> KernelTimer::collect()
     {
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
-    for (auto& r : m_done)
+    std::vector<float> elapsed(m_done.size(), 0.0f);
+    for (size_t k = 0; k < m_done.size(); k++)
         {
-        float ms = 0;
+        auto& r = m_done[k];
         if (r.stream)
             hipCheck(hipEventSynchronize(r.e1), "hipEventSynchronize");
-        hipCheck(hipEventElapsedTime(&ms, r.e0, r.e1), "hipEventElapsedTime");
-        if (ms < m_min_ms)
+        hipCheck(hipEventElapsedTime(&elapsed[k], r.e0, r.e1), "hipEventElapsedTime");
+        }
+    // a negative limit is relative: that fraction of the median sample of the same name
+    std::vector<std::pair<std::string, double>> limits;
+    auto limit_of = [&](const std::string& name) -> double
+    {
+        if (m_min_ms >= 0)
+            return m_min_ms;
+        for (auto& l : limits)
+            if (l.first == name)
+                return l.second;
+        std::vector<float> v;
+        for (size_t k = 0; k < m_done.size(); k++)
+            if (m_done[k].name == name)
+                v.push_back(elapsed[k]);
+        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        limits.emplace_back(name, -m_min_ms * (double)v[v.size() / 2]);
+        return limits.back().second;
+    };
+    for (size_t k = 0; k < m_done.size(); k++)
+        {
+        auto& r = m_done[k];
+        const float ms = elapsed[k];
+        if (ms < limit_of(r.name))
             r.name += "_skipped";
         bool found = false;
         for (auto& a : m_acc)

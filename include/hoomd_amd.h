@@ -777,9 +777,17 @@ int hmd_migrate_unpack(const hmd_migrate_unpack_args_t* args, void* stream);
  * The cell grid is cut into blocks of 2x2x2 cells.  One workgroup stages the block's 4x4x4 region
  * of cells (periodic images already shifted, so no minimum image per pair) into LDS; candidate k of
  * the region is numbered by (region cell, slot in the cell list).  A particle's row holds 16-bit
- * region-local candidate numbers at d_tile_nlist[d_head_list[i] + k], k < d_n_neigh[i], padded with
- * 0xffff to a multiple of four entries; d_tile_nlist must extend 256 entries (512 bytes) past the
- * last row (the force kernel prefetches one trip ahead).
+ * region-local candidate numbers (tile slots), k < d_n_neigh[i], padded to a multiple of four entries
+ * with the slot of a dummy far away.
+ *
+ * Row storage is neighbor-major within groups of 16 home particles: the members of a block's home
+ * cells (cells in block order, members in slot order, ghosts included) are numbered h = 0, 1, ...;
+ * group d_block_group[block] + h / 16 holds the rows of sixteen of them, cut into pieces of 16 entries
+ * (32 bytes) and interleaved: entry k of member h sits at the 16-bit offset
+ *     (((d_block_group[block] + h / 16) * row_pieces + k / 16) * 16 + h % 16) * 16 + k % 16,
+ * so the four lanes that share a home particle in the force kernel read 32 consecutive bytes and a
+ * wave (16 home particles) reads 512 consecutive bytes per trip, whatever the lengths of the rows.
+ * hmd_nlist_tiles_storage_entries() gives the size of d_tile_nlist.
  * The numbering is fixed by d_cell_size / d_cell_idx, which must not change between the build and
  * its uses.  Requirements (hmd_nlist_tiles_supported): every periodic direction has >= 3 cells and a
  * region of 64 cells holds at most `capacity` particles.
@@ -791,15 +799,24 @@ typedef struct
     hmd_index3d_t ci;
     hmd_index2d_t cli;
     unsigned int capacity;           /* candidates per region the LDS tile may hold */
-    /* Optional, both or neither (the pair-force kernel then stages a region with one round of
-       coalesced loads instead of two dependent gathers):
+    /* Required by the pair-force entry points (the kernel stages a region with one round of coalesced
+       loads from them), optional outputs of the build:
        d_cpos[cli(slot, cell)]      position (w = type word) of the member in that slot, refreshed by
                                     hmd_tile_refresh before every force launch;
-       d_slot_meta[cli(slot, cell)] x = particle index, y = n_neigh, z = row offset / 4, w unused;
+       d_slot_meta[cli(slot, cell)] x = particle index, y = n_neigh, z and w unused;
                                     written by hmd_compute_nlist_tiles. */
     const hmd_scalar4* d_cpos;
     const hmd_uint4* d_slot_meta;
+    /* Row storage (see above): first group of every block (number of blocks + 1 entries, written by
+       hmd_compute_nlist_tiles) and the number of 16-entry pieces every row has room for. */
+    const unsigned int* d_block_group;
+    unsigned int row_pieces;
     } hmd_tile_geom_t;
+
+/* Number of 16-bit entries d_tile_nlist must hold for a cell grid whose cells hold n_members particles in all
+   (owned + ghost) when rows have room for row_pieces * 16 entries; includes the slack the force kernel's
+   prefetch may touch. */
+size_t hmd_nlist_tiles_storage_entries(const hmd_index3d_t* ci, unsigned int n_members, unsigned int row_pieces);
 
 /* d_slot_of[particle index] = cli(slot, cell) for every member of the cell list (owned and ghost). */
 int hmd_tile_slots(const hmd_tile_geom_t* geom, unsigned int* d_slot_of, void* stream);
@@ -833,13 +850,16 @@ typedef struct
     const double* d_r_cut;           /* ntypes x ntypes */
     double r_buff;
     unsigned int ntypes;
-    unsigned int* d_tile_overflow;   /* two words: [0] set to 1 when a region exceeds geom.capacity (rows are then
-                                        invalid); [1] raised (atomicMax) to the largest region population, the
-                                        capacity later calls on these rows need */
+    unsigned int* d_tile_overflow;   /* two words: [0] set to 1 when a region exceeds geom.capacity or the rows
+                                        need more room than tile_nlist_entries (rows are then invalid); [1] raised
+                                        (atomicMax) to the largest region population, the capacity later calls on
+                                        these rows need */
+    size_t tile_nlist_entries;       /* size of d_tile_nlist in 16-bit entries (hmd_nlist_tiles_storage_entries) */
     } hmd_nlist_tiles_args_t;
 int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void* stream);
 
-/* Expand tile rows into particle indices: d_nlist[d_head_list[i] + k] for k < d_n_neigh[i]. */
+/* Expand tile rows into particle indices: d_nlist[d_head_list[i] + k] for k < d_n_neigh[i]
+   (the reference's layout, hoomd/md/NeighborList.h:662-739). */
 typedef struct
     {
     hmd_tile_geom_t geom;
@@ -852,7 +872,9 @@ typedef struct
     } hmd_tiles_to_rows_args_t;
 int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, void* stream);
 
-/* Pair forces from tile rows; args->d_nlist is ignored, everything else as hmd_compute_pair_forces_*. */
+/* Pair forces from tile rows; args->d_nlist, d_head_list and size_neigh_list are ignored (geom locates the rows),
+   threads_per_particle must be 0 or 4 (four lanes share a home particle), everything else as
+   hmd_compute_pair_forces_*. */
 int hmd_compute_pair_forces_lj_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom, const unsigned short* d_tile_nlist,
                                      const hmd_lj_params_t* d_params, void* stream);
 int hmd_compute_pair_forces_example_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom,

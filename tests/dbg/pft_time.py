@@ -38,7 +38,7 @@ pa.size_neigh_list = tl["tiles"].numel()
 cpos = K.tile_refresh(pos_t, tl)
 gfast = A.TileGeom.from_buffer_copy(tl["geom"])
 gfast.d_cpos, gfast.d_slot_meta, gfast.capacity = K.ptr(cpos), K.ptr(tl["slot_meta"]), cap
-for tpp in (8,):
+for tpp in (0,):
     pa.threads_per_particle = tpp
     for _ in range(3):
         A.check(fn(C.byref(pa), C.byref(gfast), K.ptr(tl["tiles"]), K.ptr(prm_t), None))

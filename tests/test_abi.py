@@ -43,6 +43,7 @@ def test_ctypes_struct_layouts_match_the_header():
         "hmd_migrate_fill_args_t": _abi.MigrateFillArgs, "hmd_unpack_ghost_init_args_t": _abi.UnpackGhostInitArgs,
         "hmd_vote_plan_args_t": _abi.VotePlanArgs, "hmd_migrate_unpack_args_t": _abi.MigrateUnpackArgs, "hmd_pack_vote_args_t": _abi.PackVoteArgs,
         "hmd_unpack_vote_args_t": _abi.UnpackVoteArgs, "hmd_ghost_send_list_args_t": _abi.GhostSendListArgs, "hmd_bond_table_args_t": _abi.BondTableArgs, "hmd_bond_args_t": _abi.BondArgs,
+        "hmd_tile_geom_t": _abi.TileGeom, "hmd_nlist_tiles_args_t": _abi.NlistTilesArgs, "hmd_tiles_to_rows_args_t": _abi.TilesToRowsArgs,
     }
     lines = ['#include "hoomd_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]
     for cname, ct in pairs.items():
