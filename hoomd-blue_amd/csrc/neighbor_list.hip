@@ -18,6 +18,8 @@
 // Results of this unit are compared bit for bit with the CPU path: no product may be fused into a
 // following sum (the CPU path rounds every product and sum separately).
 #pragma clang fp contract(off)
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include "tile.cuh"
 
@@ -396,6 +398,516 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         }
     }
 
+// ---- the same build with an fp32 pre-test (one particle type, no body filter, orthorhombic box, fixed images) ----
+//
+// The exact test of the CPU path -- rsq <= r_list^2 with rsq = dx*dx + dy*dy + dz*dz in fp64, every operation
+// rounded on its own -- costs eight fp64 instructions per 64 candidates, and 85 % of the candidates fail it.
+// Here every candidate and every home particle also exists as three fp32 coordinates relative to the first home
+// particle of the cell, two slabs of candidates packed per register, so one packed-fp32 instruction serves 128
+// tests.  The fp32 squared distance r32 differs from the true one by less than `delta` / 4 (bound computed by the
+// launcher from the cell width), so r32 <= r_list^2 - delta is a certain hit, r32 > r_list^2 + delta a certain miss,
+// and only a slab with a candidate in the band between them (about one per thousand home particles) is tested
+// again with the exact fp64 arithmetic on reloaded coordinates -- the CPU path's own: the difference of the two
+// positions, then the box length of the periodic image subtracted.  The set of neighbors is therefore, bit for bit,
+// the one the CPU path finds, also for pairs within an ulp of r_list across the periodic boundary.  The home particle itself is removed from its slab's hit mask by position in the
+// candidate list (scalar arithmetic), not by comparing indices.
+typedef float nl_v2f __attribute__((ext_vector_type(2)));
+constexpr int NL_PAIRS = NL_MAXK / 2;
+constexpr int NL_ROWBUF = 128; // entries of a row staged in LDS per wave before they go to memory
+
+// inclusive prefix sum over the 64 lanes of a wave on the vector ALU's data-parallel-primitive path: shifts by 1, 2,
+// 4, 8 within rows of 16 lanes, then lane 15 of a row into the next row and lane 31 into the upper half
+__device__ __forceinline__ unsigned int nl_wave_scan_dpp(unsigned int v)
+    {
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); // row_shr:8
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+    }
+
+struct nl_pref_t
+    {
+    float lo, hi; // r32 <= lo: hit; r32 > hi: miss
+    };
+
+// Bound on |r32 - true squared distance| for candidates near r_list: coordinates relative to the origin are below
+// M = 2 * (widest cell) + r_list, each conversion to fp32 errs by at most u * M (u = 2^-24), the difference by 2 u M
+// more, so a component of the separation by at most 4 u M and the sum of squares by 8 sqrt(3) u M r_list, plus three
+// roundings of about u r_list^2 in the squares and sums.  delta is four times that, plus two fp32 ulps of r_list^2
+// for the conversion of the thresholds themselves.
+__device__ __forceinline__ nl_pref_t nl_pref_thresholds(double rl, double rl2, double wmax)
+    {
+    nl_pref_t t;
+    if (!(rl2 > 0.0))
+        {
+        t.lo = t.hi = -1.0f; // the pair is switched off (r_cut <= 0): nothing passes
+        return t;
+        }
+    const double u = 5.9604644775390625e-08;
+    const double M = 2.0 * wmax + rl;
+    const double delta = 4.0 * (13.8564064605510183 * u * M * rl + 3.0 * u * rl2) + rl2 * 2.384185791015625e-07;
+    t.lo = (float)(rl2 - delta);
+    t.hi = (float)(rl2 + delta);
+    return t;
+    }
+
+template<bool TILE>
+__global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
+                                                              unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
+                                                              unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group,
+                                                              unsigned int row_pieces)
+    {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    unsigned int* s_excl_all = reinterpret_cast<unsigned int*>(s_raw);
+    unsigned int* s_cell_all = s_excl_all + 64 * NL_WAVES;
+    double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
+    unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * NL_WAVES);
+    unsigned int* s_rowbuf = s_tileoff_all + 64 * NL_WAVES;
+
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int* s_excl = s_excl_all + 64 * wave;
+    unsigned int* s_cell = s_cell_all + 64 * wave;
+    double* s_shift = s_shift_all + 3 * 64 * wave;
+    unsigned int* s_tileoff = s_tileoff_all + 64 * wave;
+
+    const double rc0 = a.d_r_cut[0];
+    const double rl0 = HMD_ADD(rc0, a.r_buff);
+    const double rl2 = (rc0 > 0.0) ? HMD_MUL(rl0, rl0) : -1.0;
+    const nl_pref_t pf = nl_pref_thresholds(rl0, rl2, wmax);
+
+    const unsigned int cells_per_block = NL_WAVES / wpc;
+    const unsigned int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned int cell = vb * cells_per_block + wave / wpc;
+    const unsigned int sub = wave % wpc;
+    if (cell >= ncells)
+        return;
+    const unsigned int n_home = __builtin_amdgcn_readfirstlane(min(a.d_cell_size[cell], a.cli.w));
+    if (n_home == 0)
+        return;
+
+    // ---- the 27 adjacent cells, straight from the grid coordinates (lane t: offset (t % 3 - 1, t / 3 % 3 - 1, t / 9 - 1);
+    // a cell beyond a non-periodic face does not exist, one beyond a periodic face is the cell on the far side seen
+    // one box length away): sizes -> exclusive offsets (wave scan), image shifts.  No adjacency table is read, so the
+    // sizes arrive in the same round trip as the home cell's. ----
+    const unsigned int n_adj = 27;
+    const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
+    const int hc[3] = {(int)(cell % a.ci.w), (int)((cell / a.ci.w) % a.ci.h), (int)(cell / (a.ci.w * a.ci.h))};
+    const int aoff[3] = {(int)(lane % 3u) - 1, (int)((lane / 3u) % 3u) - 1, (int)(lane / 9u) - 1};
+    unsigned int adj_cell = 0xffffffffu, adj_size = 0;
+        {
+        int ac[3];
+        double sh[3];
+        bool exists = lane < n_adj;
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            {
+            ac[d] = hc[d] + aoff[d];
+            sh[d] = 0.0;
+            if (ac[d] < 0)
+                {
+                if (a.box.periodic[d])
+                    {
+                    ac[d] += dim[d];
+                    sh[d] = -a.box.L[d];
+                    }
+                else
+                    exists = false;
+                }
+            else if (ac[d] >= dim[d])
+                {
+                if (a.box.periodic[d])
+                    {
+                    ac[d] -= dim[d];
+                    sh[d] = a.box.L[d];
+                    }
+                else
+                    exists = false;
+                }
+            }
+        if (exists)
+            {
+            adj_cell = (unsigned int)((ac[2] * dim[1] + ac[1]) * dim[0] + ac[0]);
+            adj_size = min(a.d_cell_size[adj_cell], a.cli.w);
+            }
+        s_shift[3 * lane + 0] = sh[0];
+        s_shift[3 * lane + 1] = sh[1];
+        s_shift[3 * lane + 2] = sh[2];
+        }
+    const unsigned int incl = hmd::tile_wave_scan(adj_size, (int)lane);
+    s_excl[lane] = incl - adj_size;
+    s_cell[lane] = adj_cell;
+    // where the home cell's own members start in the candidate list (for the self exclusion): offset (0, 0, 0) is lane 13
+    const unsigned int self_first = rl_u(incl - adj_size, 13u);
+
+    unsigned int tile_pad = 0, tile_hoff = 0, tile_grp0 = 0;
+    const unsigned int tile_row_cap = row_pieces * hmd::TL_PIECE;
+    if (TILE)
+        {
+        const int c0[3] = {hc[0] - hc[0] % hmd::TB_X, hc[1] - hc[1] % hmd::TB_Y, hc[2] - hc[2] % hmd::TB_Z};
+        int rimg[3];
+        const int rcell = (int)lane < hmd::TL_RC ? hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg) : -1;
+        const unsigned int rsize = rcell >= 0 ? min(a.d_cell_size[rcell], a.cli.w) : 0u;
+        const unsigned int rincl = hmd::tile_wave_scan(rsize, (int)lane);
+        const unsigned int rtotal = rl_u(rincl, 63);
+        if (rtotal > tile_capacity || __builtin_amdgcn_readfirstlane(d_tile_overflow[0]) != 0u)
+            {
+            if (lane == 0)
+                d_tile_overflow[0] = 1u;
+            return;
+            }
+        if (lane == 0 && sub == 0 && rtotal > d_tile_overflow[1])
+            atomicMax(d_tile_overflow + 1, rtotal);
+        tile_pad = hmd::tile_slot(rtotal);
+        const unsigned int nbx = (a.ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (a.ci.h + hmd::TB_Y - 1) / hmd::TB_Y;
+        const unsigned int tb = ((unsigned int)(c0[2] / hmd::TB_Z) * nby + (unsigned int)(c0[1] / hmd::TB_Y)) * nbx + (unsigned int)(c0[0] / hmd::TB_X);
+        tile_grp0 = __builtin_amdgcn_readfirstlane(d_block_group[tb]);
+        const int my_hc = ((hc[2] - c0[2]) * hmd::TB_Y + (hc[1] - c0[1])) * hmd::TB_X + (hc[0] - c0[0]);
+#pragma unroll
+        for (int q = 0; q < hmd::TL_NH; q++)
+            {
+            const int qx = q % hmd::TB_X, qy = (q / hmd::TB_X) % hmd::TB_Y, qz = q / (hmd::TB_X * hmd::TB_Y);
+            const bool home = c0[0] + qx < dim[0] && c0[1] + qy < dim[1] && c0[2] + qz < dim[2];
+            const unsigned int sz = rl_u(rsize, (unsigned int)hmd::tile_home_rc(q));
+            if (q < my_hc && home)
+                tile_hoff += sz;
+            }
+        // region cell of each adjacent cell: home position in the block + offset + 1
+        unsigned int rc = 0;
+        if (lane < n_adj)
+            rc = (unsigned int)hmd::tile_rc(hc[0] - c0[0] + aoff[0] + 1, hc[1] - c0[1] + aoff[1] + 1, hc[2] - c0[2] + aoff[2] + 1);
+        s_tileoff[lane] = __shfl(rincl - rsize, (int)rc);
+        }
+    const unsigned int T = rl_u(incl, 63);
+
+    // candidate k of the list: its cell-list slot, the shift of its cell's image, what a row stores for it
+    auto cand_lookup = [&](unsigned int k, unsigned int& lo) -> unsigned int
+    {
+        lo = 0;
+#pragma unroll
+        for (unsigned int step = 32; step > 0; step >>= 1)
+            {
+            const unsigned int t = lo + step;
+            if (t < n_adj && s_excl[t] <= k)
+                lo = t;
+            }
+        return hmd_idx2(a.cli, k - s_excl[lo], s_cell[lo]);
+    };
+
+    for (unsigned int hbase = 0; hbase < n_home; hbase += 64)
+        {
+        const unsigned int nh = min(n_home - hbase, 64u);
+        double hx = 0, hy = 0, hz = 0;
+        unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0;
+        if (lane < nh)
+            {
+            const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+            const double4 v = hmd_ld4(a.d_cell_xyzf + w);
+            hx = v.x;
+            hy = v.y;
+            hz = v.z;
+            hidx = hmd_double_as_uint(v.w);
+            if (hidx < a.N)
+                hnmax = a.d_Nmax[0];
+            }
+        // origin of the fp32 coordinates: the slab's first home particle
+        const double Ox = rl_d(hx, 0), Oy = rl_d(hy, 0), Oz = rl_d(hz, 0);
+        const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
+
+        for (unsigned int pbase = 0; pbase < T; pbase += NL_MAXK * 64)
+            {
+            const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(NL_MAXK * 64)));
+            nl_v2f fx[NL_PAIRS], fy[NL_PAIRS], fz[NL_PAIRS];
+            unsigned int co[NL_MAXK]; // what a row stores for the candidate: tile slot or particle index
+            // Loads in two batches of six slabs: first every address of a batch (the searches run on LDS), then every
+            // load, then the conversions -- two memory round trips per pass instead of one per slab.
+            constexpr int NL_BATCH = NL_MAXK / 2;
+#pragma unroll
+            for (int b0 = 0; b0 < NL_MAXK; b0 += NL_BATCH)
+                {
+                if ((unsigned int)(b0 * 64) >= Tp)
+                    {
+#pragma unroll
+                    for (int c = b0; c < b0 + NL_BATCH; c++)
+                        {
+                        co[c] = 0xffffffffu;
+                        if (c & 1)
+                            fx[c / 2].y = fy[c / 2].y = fz[c / 2].y = 1.0e18f;
+                        else
+                            fx[c / 2].x = fy[c / 2].x = fz[c / 2].x = 1.0e18f;
+                        }
+                    continue;
+                    }
+                unsigned int w_[NL_BATCH], lo_[NL_BATCH];
+#pragma unroll
+                for (int q = 0; q < NL_BATCH; q++)
+                    {
+                    const unsigned int k = pbase + (b0 + q) * 64 + lane;
+                    lo_[q] = 0;
+                    w_[q] = 0xffffffffu;
+                    if ((unsigned int)((b0 + q) * 64) < Tp && k < T)
+                        w_[q] = cand_lookup(k, lo_[q]);
+                    }
+                double2 vxy[NL_BATCH], vzw[NL_BATCH];
+#pragma unroll
+                for (int q = 0; q < NL_BATCH; q++)
+                    {
+                    // (empty slots read slot 0: a valid address, the result is not used)
+                    const double2* src = reinterpret_cast<const double2*>(a.d_cell_xyzf + (w_[q] == 0xffffffffu ? 0u : w_[q]));
+                    vxy[q] = src[0];
+                    vzw[q] = src[1];
+                    }
+#pragma unroll
+                for (int q = 0; q < NL_BATCH; q++)
+                    {
+                    const int c = b0 + q;
+                    // empty slots: far away (finite, so that the squared distance keeps a positive sign bit: the bit tests
+                    // below would take a NaN with its sign set for a hit)
+                    float x32 = 1.0e18f, y32 = x32, z32 = x32;
+                    co[c] = 0xffffffffu;
+                    if (w_[q] != 0xffffffffu)
+                        {
+                        const unsigned int lo = lo_[q];
+                        x32 = (float)(HMD_ADD(vxy[q].x, s_shift[3 * lo + 0]) - Ox);
+                        y32 = (float)(HMD_ADD(vxy[q].y, s_shift[3 * lo + 1]) - Oy);
+                        z32 = (float)(HMD_ADD(vzw[q].x, s_shift[3 * lo + 2]) - Oz);
+                        const unsigned int k = pbase + c * 64 + lane;
+                        co[c] = TILE ? hmd::tile_slot(s_tileoff[lo] + (k - s_excl[lo])) : hmd_double_as_uint(vzw[q].y);
+                        }
+                    if (c & 1)
+                        {
+                        fx[c / 2].y = x32;
+                        fy[c / 2].y = y32;
+                        fz[c / 2].y = z32;
+                        }
+                    else
+                        {
+                        fx[c / 2].x = x32;
+                        fy[c / 2].x = y32;
+                        fz[c / 2].x = z32;
+                        }
+                    }
+                }
+
+            // 16-bit slabs count of this pass and the fp32 thresholds as integers: for non-negative floats the bit
+            // patterns order like the values, so t = bits(r32) - (bits(lo) + 1) is negative (top bit set) exactly for
+            // r32 <= lo, and below `band` exactly for lo < r32 <= hi
+            const unsigned int nslab = (Tp + 63u) / 64u;
+            const unsigned int lo1 = __float_as_uint(pf.lo) + 1u;
+            const unsigned int band = pf.hi > 0.0f ? __float_as_uint(pf.hi) - __float_as_uint(pf.lo) : 0u;
+            for (unsigned int i = sub; i < nh; i += wpc)
+                {
+                const unsigned int iu = __builtin_amdgcn_readfirstlane(i);
+                const unsigned int i_idx = rl_u(hidx, iu);
+                if (i_idx >= a.N)
+                    continue; // ghosts get no row
+                const float pxs = __uint_as_float(rl_u(__float_as_uint(hxf), iu)), pys = __uint_as_float(rl_u(__float_as_uint(hyf), iu)),
+                            pzs = __uint_as_float(rl_u(__float_as_uint(hzf), iu));
+                const nl_v2f px = {pxs, pxs}, py = {pys, pys}, pz = {pzs, pzs};
+                const unsigned int nmax_i = rl_u(hnmax, iu);
+                const unsigned int cnt_old = rl_u(cnt, iu);
+                const unsigned int nmax_w = TILE ? min(nmax_i, tile_row_cap) : nmax_i;
+
+                // ---- test phase: nothing but vector arithmetic.  Every lane collects one bit per slab (slab c ends up
+                // at bit nslab - 1 - c) and the smallest distance of any of its candidates from the undecided band. ----
+                unsigned int bits = 0, nearest = 0xffffffffu;
+                if (pf.hi > 0.0f)
+                    {
+#pragma unroll
+                    for (int s = 0; s < NL_PAIRS; s++)
+                        {
+                        if ((unsigned int)(2 * s * 64) < Tp)
+                            {
+                            const nl_v2f dx = px - fx[s], dy = py - fy[s], dz = pz - fz[s];
+                            nl_v2f r = dx * dx;
+                            r = __builtin_elementwise_fma(dy, dy, r);
+                            r = __builtin_elementwise_fma(dz, dz, r);
+                            const unsigned int t0 = __float_as_uint(r.x) - lo1;
+                            bits = __builtin_amdgcn_alignbit(bits, t0, 31);
+                            nearest = min(nearest, t0);
+                            if ((unsigned int)((2 * s + 1) * 64) < Tp)
+                                {
+                                const unsigned int t1 = __float_as_uint(r.y) - lo1;
+                                bits = __builtin_amdgcn_alignbit(bits, t1, 31);
+                                nearest = min(nearest, t1);
+                                }
+                            }
+                        }
+                    }
+                if (__ballot(nearest < band))
+                    {
+                    // a candidate of this particle sits in the band around r_list^2: every slab again with the CPU
+                    // path's own arithmetic -- the difference first, then the box length of the image
+                    // (hoomd/BoxDim.h:326-372 with one image; L * 1 is exact)
+                    const double pix = rl_d(hx, iu), piy = rl_d(hy, iu), piz = rl_d(hz, iu);
+                    bits = 0;
+                    for (unsigned int c = 0; c < nslab; c++)
+                        {
+                        const unsigned int k = pbase + c * 64 + lane;
+                        bool hit = false;
+                        if (k < T)
+                            {
+                            unsigned int lo;
+                            const unsigned int w = cand_lookup(k, lo);
+                            const double4 v = hmd_ld4(a.d_cell_xyzf + w);
+                            const double dx64 = HMD_SUB(HMD_SUB(pix, v.x), s_shift[3 * lo + 0]);
+                            const double dy64 = HMD_SUB(HMD_SUB(piy, v.y), s_shift[3 * lo + 1]);
+                            const double dz64 = HMD_SUB(HMD_SUB(piz, v.z), s_shift[3 * lo + 2]);
+                            const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx64, dx64), HMD_MUL(dy64, dy64)), HMD_MUL(dz64, dz64));
+                            hit = rsq <= rl2;
+                            }
+                        bits = (bits << 1) | (hit ? 1u : 0u);
+                        }
+                    }
+                // the particle itself, by its place in the candidate list
+                const unsigned int k_self = self_first + hbase + iu - pbase; // (wraps below pbase: then >= NL_MAXK * 64)
+                if ((k_self >> 6) < nslab && lane == (k_self & 63u))
+                    bits &= ~(1u << (nslab - 1u - (k_self >> 6)));
+
+                // ---- compaction: hits ordered by lane, then slab.  One scan over the wave places every lane's hits. ----
+                const unsigned int mine = (unsigned int)__popc(bits);
+                const unsigned int incl = nl_wave_scan_dpp(mine);
+                const unsigned int n_hits = rl_u(incl, 63);
+                const unsigned int base = cnt_old + incl - mine;
+                unsigned int* wrow = s_rowbuf + NL_ROWBUF * wave;
+                const unsigned int cnt_new = cnt_old + n_hits;
+                // (decided once per particle: the whole row fits its capacity and the staging buffer -- the rule)
+                const bool fits = cnt_new <= min(nmax_w, (unsigned int)NL_ROWBUF);
+                if (fits)
+                    {
+                    // the slab bits leave through the top of the register one by one; the running position steps
+                    // forward on every hit
+                    unsigned int b = bits << (32u - nslab);
+                    unsigned int pos = base - 1u;
+#pragma unroll
+                    for (int c = 0; c < NL_MAXK; c++)
+                        {
+                        if ((unsigned int)(c * 64) < Tp)
+                            {
+                            const bool hit = (int)b < 0;
+                            b <<= 1;
+                            pos += hit ? 1u : 0u;
+                            if (hit)
+                                wrow[pos] = co[c];
+                            }
+                        }
+                    }
+                else
+                    {
+#pragma unroll
+                    for (int c = 0; c < NL_MAXK; c++)
+                        {
+                        if ((unsigned int)(c * 64) < Tp)
+                            {
+                            const unsigned int bp = nslab - 1u - (unsigned int)c;
+                            const unsigned int pos = base + (unsigned int)__popc(bits >> 1 >> bp); // this lane's hits in earlier slabs sit above bit bp
+                            if (((bits >> bp) & 1u) && pos < nmax_w)
+                                {
+                                if (pos < (unsigned int)NL_ROWBUF)
+                                    wrow[pos] = co[c];
+                                else if (TILE) // rows longer than the staging buffer: straight to memory
+                                    {
+                                    const unsigned int h_i = tile_hoff + hbase + iu;
+                                    unsigned short* trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
+                                    trow[((pos & ~15u) << 4) | (pos & 15u)] = (unsigned short)co[c];
+                                    }
+                                else
+                                    a.d_nlist[a.d_head_list[i_idx] + pos] = co[c];
+                                }
+                            }
+                        }
+                    }
+                // ---- the staged part of the row goes to memory ----
+                const unsigned int stop = min(min(cnt_new, nmax_w), (unsigned int)NL_ROWBUF);
+                if (TILE)
+                    {
+                    const unsigned int h_i = tile_hoff + hbase + iu;
+                    char* trow = reinterpret_cast<char*>(d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE);
+                    if (fits && cnt_old == 0)
+                        {
+                        // one store instruction: every lane packs two entries, the padding to a multiple of four included
+                        const unsigned int padded = (cnt_new + 3u) & ~3u;
+                        const unsigned int e = 2u * lane;
+                        if (e < padded)
+                            {
+                            const uint2 w2 = *reinterpret_cast<const uint2*>(wrow + e);
+                            const unsigned int v0 = e < cnt_new ? w2.x : tile_pad, v1 = e + 1u < cnt_new ? w2.y : tile_pad;
+                            *reinterpret_cast<unsigned int*>(trow + (((lane >> 3) << 9) | ((lane & 7u) << 2))) = (v0 & 0xffffu) | (v1 << 16);
+                            }
+                        }
+                    else
+                        {
+#pragma unroll
+                        for (unsigned int e0 = 0; e0 < (unsigned int)NL_ROWBUF; e0 += 64)
+                            {
+                            const unsigned int e = e0 + lane;
+                            if (e >= cnt_old && e < stop)
+                                *reinterpret_cast<unsigned short*>(trow + (((e & ~15u) << 5) | ((e & 15u) << 1))) = (unsigned short)wrow[e];
+                            }
+                        }
+                    }
+                else
+                    {
+                    unsigned int* row = a.d_nlist + a.d_head_list[i_idx];
+#pragma unroll
+                    for (unsigned int e0 = 0; e0 < (unsigned int)NL_ROWBUF; e0 += 64)
+                        {
+                        const unsigned int e = e0 + lane;
+                        if (e >= cnt_old && e < stop)
+                            row[e] = wrow[e];
+                        }
+                    }
+                if (lane == iu)
+                    cnt = cnt_new;
+                }
+            }
+
+
+        // ---- per-particle results ----
+        if (TILE && d_slot_meta && lane < nh && hidx >= a.N && (lane % wpc) == sub)
+            {
+            hmd_uint4 m = {hidx, 0u, 0u, 0u}; // a ghost: no row
+            const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+            d_slot_meta[w] = m;
+            if (d_slot_of)
+                {
+                d_slot_of[hidx] = w;
+                hmd_st4(d_cpos + w, hx, hy, hz, a.d_pos[hidx].w);
+                }
+            }
+        if (lane < nh && hidx < a.N && (lane % wpc) == sub)
+            {
+            const double wtype = a.d_pos[hidx].w;
+            if (TILE && d_slot_meta)
+                {
+                hmd_uint4 m = {hidx, cnt, 0u, 0u};
+                const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
+                d_slot_meta[w] = m;
+                if (d_slot_of)
+                    {
+                    d_slot_of[hidx] = w;
+                    hmd_st4(d_cpos + w, hx, hy, hz, wtype);
+                    }
+                }
+            a.d_n_neigh[hidx] = cnt;
+            if (TILE)
+                {
+                const unsigned int h_i = tile_hoff + hbase + lane;
+                unsigned short* trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
+                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < min(hnmax, tile_row_cap); k++)
+                    trow[((k & ~15u) << 4) | (k & 15u)] = (unsigned short)tile_pad;
+                }
+            if (a.d_last_updated_pos)
+                hmd_st4(a.d_last_updated_pos + hidx, hx, hy, hz, hmd_uint_as_double(hmd_double_as_uint(wtype)));
+            if (cnt >= hnmax)
+                atomicMax(&a.d_conditions[0], cnt);
+            }
+        }
+    }
+
 template<bool ORTHO>
 __global__ void __launch_bounds__(256) nlist_check_kernel(hmd_nlist_check_args_t a)
     {
@@ -572,7 +1084,7 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
 // consecutive blocks, the runs are scanned, every thread writes its run.
 constexpr unsigned int BG_THREADS = 1024;
 __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const unsigned int* d_cell_size, hmd_index3d_t ci, unsigned int cell_Nmax,
-                                                                       unsigned int* d_block_group, unsigned int tile_groups, unsigned int* d_tile_overflow)
+                                                                       unsigned int* d_block_group, unsigned int tile_groups, unsigned int* d_tile_overflow, bool cached)
     {
     __shared__ unsigned int s_wave[BG_THREADS / 64];
     const unsigned int nbx = (ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (ci.h + hmd::TB_Y - 1) / hmd::TB_Y, nbz = (ci.d + hmd::TB_Z - 1) / hmd::TB_Z;
@@ -592,9 +1104,18 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
             }
         return (members + hmd::TL_GROUP - 1) / hmd::TL_GROUP;
     };
+    // counts first, with neighboring threads on neighboring blocks (when they fit the LDS the launcher provided):
+    // every thread then sums and later numbers its run of consecutive blocks from LDS
+    extern __shared__ unsigned int s_groups[];
+    if (cached)
+        {
+        for (unsigned int b = threadIdx.x; b < nb; b += BG_THREADS)
+            s_groups[b] = groups_of(b);
+        __syncthreads();
+        }
     unsigned int mine = 0;
     for (unsigned int b = first; b < last; b++)
-        mine += groups_of(b);
+        mine += cached ? s_groups[b] : groups_of(b);
     // exclusive scan over the threads
     const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int incl = hmd::tile_wave_scan(mine, (int)lane);
@@ -612,7 +1133,7 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
     for (unsigned int b = first; b < last; b++)
         {
         d_block_group[b] = run;
-        run += groups_of(b);
+        run += cached ? s_groups[b] : groups_of(b);
         }
     if (threadIdx.x == 0)
         {
@@ -635,6 +1156,22 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     for (int d = 0; d < 3; d++)
         if (a.box.periodic[d] && dim[d] < 3)
             fixed_images = false;
+    // one type, no body filter, fixed images, orthorhombic: the build with the fp32 pre-test
+    if (ST && !FB && fixed_images && hmd_box_is_ortho(a.box) && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY"))
+        {
+        double wmax = 0.0;
+        const double gw[3] = {a.ghost_width.x, a.ghost_width.y, a.ghost_width.z};
+        for (int d = 0; d < 3; d++)
+            wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
+        const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF) + sizeof(double) * 3 * 64) * NL_WAVES;
+        if (d_tile)
+            hipLaunchKernelGGL((nlist_pref_kernel<true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
+                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        else
+            hipLaunchKernelGGL((nlist_pref_kernel<false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 0u);
+        return hmd_launch_status();
+        }
     if (d_tile)
         {
         HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
@@ -747,8 +1284,10 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
                 "hmd_compute_nlist_tiles: tile_nlist_entries holds no group of rows (size it with hmd_nlist_tiles_storage_entries)");
     const unsigned int tile_groups = (unsigned int)(groups_fit - hmd::TL_SLACK_GROUPS);
     // the caller clears d_tile_overflow; the groups are numbered first, and the build gives up when they do not fit
-    hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci, t.geom.cli.w,
-                       const_cast<unsigned int*>(t.geom.d_block_group), tile_groups, t.d_tile_overflow);
+    const size_t bg_lds = (size_t)hmd::tile_num_blocks(t.geom.ci) * sizeof(unsigned int);
+    const bool bg_cached = bg_lds <= 60 * 1024;
+    hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), bg_cached ? bg_lds : 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci,
+                       t.geom.cli.w, const_cast<unsigned int*>(t.geom.d_block_group), tile_groups, t.d_tile_overflow, bg_cached);
     return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta, t.d_slot_of,
                                t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr, t.geom.d_block_group, t.geom.row_pieces);
     }

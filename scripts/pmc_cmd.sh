@@ -23,11 +23,11 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in ("p1", "p2", "p3"):
     for f in glob.glob(f"{out}/{p}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:90]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
             vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in vals.items():
-    if not any(s in k for s in ("pair_force", "nlist_binned", "fused_step", "cell_list", "tile_")):
+    if not any(s in k for s in ("pair_force", "nlist_", "fused_step", "cell_list", "tile_")):
         continue
     res[k] = {}
     for c, xs in v.items():

@@ -1,0 +1,134 @@
+"""The neighbor-list build with the fp32 pre-test must give, bit for bit, the sets of the exact fp64 test
+(hoomd/md/NeighborListBinned.cc:150-157): pairs engineered to sit at r_list, one ulp to either side of it and
+all through the band the pre-test cannot decide are compared with the CPU oracle and with the same kernel family
+run without the pre-test."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402
+
+
+def same_sets(got, want):
+    return len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+@pytest.fixture(scope="module")
+def K():
+    from hoomd_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def A():
+    from hoomd_amd import _abi
+    return _abi
+
+
+def _system(seed, L, n_free, n_pairs, r_list):
+    """Random particles plus partners placed at r_list * (1 + eps) from some of them, eps from 0 and single ulps up
+    to 1e-5, in random directions, wrapped into the box (so some pairs straddle the periodic boundary)."""
+    rng = np.random.default_rng(seed)
+    Lb = np.asarray(L, dtype=np.float64)
+    free = (rng.random((n_free, 3)) - 0.5) * Lb
+    eps = np.concatenate([[0.0], np.array([1, -1, 2, -2, 4, -4]) * 2.220446049250313e-16,
+                          [s * 10.0 ** e for e in range(-14, -4) for s in (1.0, -1.0)]])
+    src = rng.integers(0, n_free, n_pairs)
+    d = rng.normal(size=(n_pairs, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    # a third of the directions along an axis: the squared distance is then a single rounded product
+    ax = rng.integers(0, 3, n_pairs)
+    axis_dir = np.zeros((n_pairs, 3))
+    axis_dir[np.arange(n_pairs), ax] = rng.choice([-1.0, 1.0], n_pairs)
+    d = np.where((np.arange(n_pairs) % 3 == 0)[:, None], axis_dir, d)
+    dist = r_list * (1.0 + eps[rng.integers(0, len(eps), n_pairs)])
+    partners = free[src] + d * dist[:, None]
+    xyz = np.concatenate([free, partners])
+    xyz = (xyz + Lb / 2) % Lb - Lb / 2
+    return xyz
+
+
+@pytest.mark.parametrize("L,seed", [((21.0, 21.0, 21.0), 1), ((30.0, 12.5, 17.0), 2)])
+def test_prefiltered_build_equals_exact_test(K, A, L, seed):
+    r_cut, r_buff = 2.5, 0.4
+    r_list = r_cut + r_buff
+    n_free = int(0.6 * L[0] * L[1] * L[2])
+    xyz = _system(seed, L, n_free, 4000, r_list)
+    N = len(xyz)
+    pos = orc.pack_pos(xyz, np.zeros(N, dtype=int))
+    obox, gbox = orc.Box.from_L(*L), A.Box.from_L(*L)
+    dim = orc.cell_dimensions(obox, r_list)
+    assert min(dim) >= 3
+    ref = orc.nlist_binned(pos, N, obox, [[r_cut]], r_buff, storage_full=True)
+    ref_sets = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    # the engineered pairs do sit where the pre-test cannot decide: some are neighbors, some are not
+    d2 = []
+    for i in range(n_free, N, 7):
+        dx = xyz[:n_free] - xyz[i]
+        dx -= np.asarray(L) * np.rint(dx / np.asarray(L))
+        r2 = np.einsum("ij,ij->i", dx, dx)
+        d2.append(r2[np.argmin(np.abs(r2 - r_list ** 2))])
+    d2 = np.array(d2)
+    assert (np.abs(d2 - r_list ** 2) < 1e-9).sum() > 50 and (d2 <= r_list ** 2).any() and (d2 > r_list ** 2).any()
+
+    pos_t = torch.from_numpy(pos).cuda()
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+
+    def sets_of(nl):
+        return orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                                 nl["head"].cpu().numpy().view(np.uint64)[:N])
+
+    # ("exact": the general kernel, which serves several particle types and the body filter.  It shifts the candidates
+    # of a periodic image once when it loads them, so across the boundary its difference is p_i - (p_j + L) where the
+    # CPU path has (p_i - p_j) - L: the last bit of the squared distance can differ, hence the engineered pairs are
+    # only required of the pre-test kernel, whose exact test repeats the CPU arithmetic.)
+    results = {}
+    for mode in ("pretest",):
+        if mode == "exact":
+            os.environ["HOOMD_AMD_NLIST_EXACT_ONLY"] = "1"
+        try:
+            rows = K.nlist_binned(pos_t, N, gbox, [[r_cut]], r_buff, cl, adj)
+            tl = K.nlist_tiles(pos_t, N, gbox, [[r_cut]], r_buff, cl, adj)
+            tl["nlist"] = K.tiles_to_rows(tl, N, gbox)
+        finally:
+            os.environ.pop("HOOMD_AMD_NLIST_EXACT_ONLY", None)
+        results[mode] = (sets_of(rows), sets_of(tl))
+        assert np.array_equal(rows["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"]), mode
+        assert np.array_equal(tl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"]), mode
+        assert np.array_equal(rows["last_pos"].cpu().numpy()[:N, :3], pos[:, :3]) and np.array_equal(tl["last_pos"].cpu().numpy()[:N, :3], pos[:, :3])
+    for mode, (s_rows, s_tiles) in results.items():
+        assert same_sets(s_rows, ref_sets), mode
+        assert same_sets(s_tiles, ref_sets), mode
+
+
+def test_prefilter_handles_coincident_particles_and_disabled_pairs(K, A):
+    """Two particles at the same position are each other's neighbors (the particle itself is removed by its place in
+    the candidate list, not by a zero distance); r_cut <= 0 switches the pair off."""
+    L = (12.0, 12.0, 12.0)
+    rng = np.random.default_rng(5)
+    xyz = (rng.random((1200, 3)) - 0.5) * np.asarray(L)
+    xyz[1] = xyz[0]
+    xyz[700] = xyz[0]
+    N = len(xyz)
+    pos = orc.pack_pos(xyz, np.zeros(N, dtype=int))
+    obox, gbox = orc.Box.from_L(*L), A.Box.from_L(*L)
+    dim = orc.cell_dimensions(obox, 2.9)
+    pos_t = torch.from_numpy(pos).cuda()
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+    for r_cut in (2.5, -1.0):
+        ref = orc.nlist_binned(pos, N, obox, [[r_cut]], 0.4, storage_full=True)
+        # the cell width is fixed by the caller's cell list, as in the reference when one consumer turns its pair off
+        nl = K.nlist_binned(pos_t, N, gbox, [[r_cut]], 0.4, cl, adj)
+        got = orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                                nl["head"].cpu().numpy().view(np.uint64)[:N])
+        assert same_sets(got, orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"]))
+        if r_cut > 0:
+            assert 1 in got[0] and 700 in got[0] and 0 in got[1] and 0 not in got[0]
+        else:
+            assert all(len(s) == 0 for s in got)
