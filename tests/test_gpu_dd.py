@@ -54,3 +54,25 @@ def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, 
     assert np.abs(a["velocity"] - b["velocity"]).max() < 1e-6
     if not sorter:
         assert len(set(b["builds"])) == 1 and b["builds"][0] == a["builds"][0]
+    # ... and the CPU path itself (half list + third law on one domain) from the same start: the decomposed GPU
+    # trajectory is the reference algorithm's trajectory, not merely the single-domain GPU run's
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "scripts"))
+    import hoomd_amd
+    import lj_liquid
+    from oracle import oracle as orc
+    snap = lj_liquid.make_snapshot(hoomd_amd, n, kT=1.5, seed=11)
+    snap.particles.position[:] += np.random.default_rng(2).normal(0, 0.05, snap.particles.position.shape)
+    snap.wrap()
+    vel = np.concatenate([snap.particles.velocity, snap.particles.mass[:, None]], axis=1)
+    o = orc.Sim(orc.pack_pos(snap.particles.position, snap.particles.typeid), vel, snap.configuration.box[:3], shift_mode=orc.SHIFT_SHIFT)
+    o.run(0)
+    assert np.allclose(o.energies(), b["e0"], rtol=1e-10)
+    o.run(steps)
+    op, ov, oi, _ = o.get()
+    # the snapshot built here carries the images of its own wrap(); the workers start from the same wrapped state
+    uo = op[:, :3] + (oi + snap.particles.image) * L
+    assert np.abs(uo - ub).max() < 1e-7
+    assert np.abs(ov[:, :3] - b["velocity"]).max() < 1e-6
+    assert np.allclose(o.energies(), b["e1"], rtol=1e-7)
+    if not sorter:
+        assert o.stats()["num_builds"] == b["builds"][0]
