@@ -143,6 +143,9 @@ class GSDFile:
             f.write(a.tobytes())
         if not len(entries):  # an empty frame still counts: gsd.c does not allow it either
             raise RuntimeError("a frame needs at least one chunk")
+        # the entries of a frame go into the index ordered by name id: gsd_find_chunk (hoomd/extern/gsd.c) bisects
+        # the index on (frame, id), and gsd_end_frame sorts its buffered entries the same way before writing them
+        entries = entries[np.argsort(entries["id"], kind="stable")]
         header_dirty = False
         if new_names:
             add = b"".join(n.encode() + b"\0" for n in new_names)

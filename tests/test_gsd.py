@@ -148,6 +148,41 @@ def test_appending_to_each_others_files(tmp_path):
     r.close()
 
 
+@needs_ref
+def test_chunks_written_out_of_name_order_are_found_by_the_reference_library(tmp_path):
+    """A name that first appears in a later frame gets the highest id; written before the older names, its index
+    entry would precede theirs.  The reference looks chunks up by bisection on (frame, id), so the index must hold
+    every frame's entries in id order whatever order they were written in."""
+    fn = str(tmp_path / "order.gsd")
+    rng = np.random.default_rng(8)
+    old = [f"particles/chunk_{c:02d}" for c in range(12)]
+    new = [f"log/new_{c:02d}" for c in range(5)]
+    data = [[(n, rng.random(4).astype(np.float32)) for n in old]]
+    # frame 1: new names first, then the old ones in reverse; frame 2: interleaved, one more new name in the middle
+    data.append([(n, rng.random(3)) for n in new] + [(n, rng.random(4).astype(np.float32)) for n in reversed(old)])
+    mixed = [n for pair in zip(reversed(new), old) for n in pair] + ["log/newest"] + old[len(new):]
+    data.append([(n, rng.integers(0, 9, 6).astype(np.int32)) for n in mixed])
+    with GSDFile(fn, "w", application="test", schema="hoomd", schema_version=(1, 4)) as f:
+        for chunks in data:
+            for name, a in chunks:
+                f.write_chunk(name, a)
+            f.end_frame()
+        idx = f._index[: sum(len(c) for c in data)]
+        assert all(np.all(np.diff(idx["id"][idx["frame"] == fr].astype(np.int64)) > 0) for fr in range(3))
+    r = Ref()
+    r.open(fn, READONLY)
+    assert r.nframes() == 3
+    for fr, chunks in enumerate(data):
+        for name, a in chunks:
+            assert same(r.read(fr, name), a), (fr, name)
+    assert r.read(0, "log/new_00") is None and r.read(1, "log/newest") is None
+    r.close()
+    with GSDFile(fn, "r") as f:
+        for fr, chunks in enumerate(data):
+            for name, a in chunks:
+                assert same(f.read_chunk(fr, name), a), (fr, name)
+
+
 def test_golden_file_written_by_the_reference_library():
     # tests/golden/make_golden.py wrote it through hoomd/extern/gsd.c: two frames of a 5-particle system
     with GSDFile(GOLDEN, "r") as f:
