@@ -293,6 +293,11 @@ def main():
                 "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "fp64_frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
             },
         }
+        if decomposition is not None:
+            out["config"]["decomposition"] = {
+                "backend": dist.get_backend(), "exchange_stream_high_priority": bool(cell._cpp_obj.comm_stream_high_priority),
+                "steps_with_forces_overlapping_the_exchange": int(cell._cpp_obj.num_overlapped),
+                "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.exchange.n_vote_exchanges)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

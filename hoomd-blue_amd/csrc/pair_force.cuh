@@ -16,11 +16,29 @@
 #define HMD_PAIR_FORCE_CUH
 
 #include "common.cuh"
-#include "evaluators.cuh"
+#include <type_traits>
+#include <utility>
 
 namespace hmd
     {
 constexpr int PF_BLOCK = 256;
+
+// The kernels are templates over an evaluator class of the reference's shape (hoomd/md/EvaluatorPairLJ.h:35-81,
+// example_plugins/pair_plugin/EvaluatorPairExample.h:33-167):
+//   struct param_type            plain data, one per type pair, copied to LDS by the kernel
+//   Evaluator(rsq, rcutsq, const param_type&)
+//   static bool needsCharge();   void setCharge(qi, qj);
+//   bool evalForceAndEnergy(Scalar& force_divr, Scalar& pair_eng, bool energy_shift);
+// Optionally an evaluator offers evalUnshiftedBranchFree(force_divr, pair_eng) const: force and energy of the unshifted
+// potential that vanish by themselves outside the cutoff; the kernels use it when it exists.
+template<class Ev, class = void> struct has_branch_free
+    {
+    static constexpr bool value = false;
+    };
+template<class Ev> struct has_branch_free<Ev, decltype(std::declval<const Ev&>().evalUnshiftedBranchFree(std::declval<double&>(), std::declval<double&>()))>
+    {
+    static constexpr bool value = true;
+    };
 
 __device__ __forceinline__ unsigned int pf_xcd_remap(unsigned int b, unsigned int nb)
     {
@@ -354,6 +372,31 @@ int pf_launch2(const hmd_pair_args_t& a, const typename Ev::param_type* d_params
         }
     }
 
+// needsCharge() of an evaluator as the host sees it.  The contract declares it a device function (an evaluator written
+// for the reference has it so), which host code cannot call: a one-thread kernel asks once per evaluator and process.
+// If the question cannot be asked the answer is "yes" (the charge array is then required, which is always safe).
+static __device__ int pf_query_word;
+template<class Ev> __global__ void pf_needs_charge_kernel()
+    {
+    pf_query_word = Ev::needsCharge() ? 1 : 0;
+    }
+template<class Ev> bool pf_needs_charge(hipStream_t s)
+    {
+    static const bool answer = [s]()
+    {
+        int h = 1;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            return true;
+        hipLaunchKernelGGL(pf_needs_charge_kernel<Ev>, dim3(1), dim3(1), 0, s);
+        if (hipMemcpyFromSymbolAsync(&h, HIP_SYMBOL(pf_query_word), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess
+            || hipStreamSynchronize(s) != hipSuccess)
+            return true;
+        return h != 0;
+    }();
+    return answer;
+    }
+
 // Driver shared by every evaluator's extern "C" entry point.
 template<class Ev> int launch_pair_forces(const hmd_pair_args_t* args, const typename Ev::param_type* d_params, void* stream, const char* who)
     {
@@ -364,7 +407,7 @@ template<class Ev> int launch_pair_forces(const hmd_pair_args_t* args, const typ
     HMD_REQUIRE(a.shift_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces: shift_mode must be 0 (none), 1 (shift) or 2 (xplor)");
     HMD_REQUIRE(a.shift_mode != 2 || a.d_ronsq, HMD_ERR_INVALID_ARGUMENT, "pair forces: xplor needs d_ronsq");
     HMD_REQUIRE(!a.compute_virial || a.d_virial, HMD_ERR_INVALID_ARGUMENT, "pair forces: compute_virial needs d_virial");
-    HMD_REQUIRE(!Ev::needsCharge() || a.d_charge, HMD_ERR_INVALID_ARGUMENT, "pair forces: this evaluator needs d_charge");
+    HMD_REQUIRE(a.d_charge || !pf_needs_charge<Ev>((hipStream_t)stream), HMD_ERR_INVALID_ARGUMENT, "pair forces: this evaluator needs d_charge");
     HMD_REQUIRE(a.ntypes >= 1, HMD_ERR_INVALID_ARGUMENT, "pair forces: ntypes must be >= 1");
     unsigned int tpp = a.threads_per_particle ? a.threads_per_particle : 8;
     HMD_REQUIRE(tpp <= 64 && (tpp & (tpp - 1)) == 0, HMD_ERR_INVALID_ARGUMENT,

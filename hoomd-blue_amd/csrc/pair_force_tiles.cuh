@@ -622,7 +622,8 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
     HMD_REQUIRE(a.shift_mode <= 2, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): shift_mode must be 0, 1 or 2");
     HMD_REQUIRE(a.shift_mode != 2 || a.d_ronsq, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): xplor needs d_ronsq");
     HMD_REQUIRE(!a.compute_virial || a.d_virial, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles): compute_virial needs d_virial");
-    HMD_REQUIRE(!Ev::needsCharge(), HMD_ERR_UNSUPPORTED, "pair forces (tiles): evaluators that need charges use the row-based entry point");
+    HMD_REQUIRE(!pf_needs_charge<Ev>((hipStream_t)stream), HMD_ERR_UNSUPPORTED,
+                "pair forces (tiles): evaluators that need charges use the row-based entry point");
     unsigned int cap = 0;
     const int rc = hmd_nlist_tiles_supported(&g.ci, &a.box, g.cli.w, a.ntypes, &cap);
     if (rc != HMD_OK)

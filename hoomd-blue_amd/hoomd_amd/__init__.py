@@ -11,12 +11,12 @@ __version__ = "0.1.0"
 
 from . import _abi  # noqa: F401  (fails loudly when libhoomd_amd.so is missing)
 from . import _hoomd_amd  # noqa: F401  (fails loudly when the host module is missing)
-from . import device, error, filter, md, pair_plugin, trigger, tune, write
+from . import device, error, filter, md, trigger, tune, write
 from .box import Box
 from .simulation import Simulation
 from .snapshot import Snapshot
 
-__all__ = ["Box", "Simulation", "Snapshot", "comm", "device", "error", "filter", "md", "pair_plugin", "trigger", "tune", "write"]
+__all__ = ["Box", "Simulation", "Snapshot", "comm", "device", "error", "filter", "md", "trigger", "tune", "write"]
 
 
 def __getattr__(name):

@@ -282,7 +282,9 @@ class Simulation:
         while done < steps:
             t0 = self.timestep
             k = next((j for j in range(1, steps - done + 1) if any(w.trigger(t0 + j) for w in writers)), steps - done)
-            self._cpp_sys.run(k)
+            # only the first piece is a run's start (forced migration, forces of the initial state); writers read
+            # the state between the pieces and change nothing
+            self._cpp_sys.run(k, done == 0)
             wall += self._cpp_sys.getLastWalltime()
             done += k
             for w in writers:

@@ -1184,163 +1184,9 @@ class ForceCompute : public Compute
     };
 
 // ---------------------------------------------------------------------------------------------
-// PotentialPairGPU<evaluator> (hoomd/md/PotentialPair.h, hoomd/md/PotentialPairGPU.h).
-// The host-side evaluator traits carry the parameter block, the LRC integrals and the symbol of
-// the matching kernel driver (one extern "C" entry point per evaluator).
+// PotentialPair<evaluator> / PotentialPairGPU<evaluator> are header-only templates for evaluators built in and out of
+// the tree: include/hoomd/md/PotentialPair.h, include/hoomd/md/PotentialPairGPU.h.
 // ---------------------------------------------------------------------------------------------
-struct EvaluatorLJHost
-    {
-    typedef hmd_lj_params_t param_type;
-    static const char* getName()
-        {
-        return "lj";
-        }
-    static int launch(const hmd_pair_args_t* a, const param_type* p, void* s)
-        {
-        return hmd_compute_pair_forces_lj(a, p, s);
-        }
-    static int launchTiles(const hmd_pair_args_t* a, const hmd_tile_geom_t* g, const unsigned short* t, const param_type* p, void* s)
-        {
-        return hmd_compute_pair_forces_lj_tiles(a, g, t, p, s);
-        }
-    //! hoomd/md/EvaluatorPairLJ.h:213-248
-    static Scalar energyLRC(Scalar rcutsq, const param_type& p);
-    static Scalar pressureLRC(Scalar rcutsq, const param_type& p);
-    //! pair energy on the host (hoomd/md/EvaluatorPairLJ.h:165-207), for computeEnergyBetweenSets
-    static bool evalEnergy(Scalar rsq, Scalar rcutsq, const param_type& p, bool energy_shift, Scalar& pair_eng)
-        {
-        const Scalar lj1 = p.epsilon_x_4 * p.sigma_6 * p.sigma_6, lj2 = p.epsilon_x_4 * p.sigma_6;
-        if (!(rsq < rcutsq) || lj1 == 0)
-            return false;
-        const Scalar r2inv = 1.0 / rsq, r6inv = r2inv * r2inv * r2inv;
-        pair_eng = r6inv * (lj1 * r6inv - lj2);
-        if (energy_shift)
-            {
-            const Scalar rcut2inv = 1.0 / rcutsq, rcut6inv = rcut2inv * rcut2inv * rcut2inv;
-            pair_eng -= rcut6inv * (lj1 * rcut6inv - lj2);
-            }
-        return true;
-        }
-    };
-
-struct EvaluatorExampleHost
-    {
-    typedef hmd_example_params_t param_type;
-    static const char* getName()
-        {
-        return "example_pair";
-        }
-    static int launch(const hmd_pair_args_t* a, const param_type* p, void* s)
-        {
-        return hmd_compute_pair_forces_example(a, p, s);
-        }
-    static int launchTiles(const hmd_pair_args_t* a, const hmd_tile_geom_t* g, const unsigned short* t, const param_type* p, void* s)
-        {
-        return hmd_compute_pair_forces_example_tiles(a, g, t, p, s);
-        }
-    static Scalar energyLRC(Scalar, const param_type&)
-        {
-        return 0;
-        }
-    static Scalar pressureLRC(Scalar, const param_type&)
-        {
-        return 0;
-        }
-    //! example_plugins/pair_plugin/EvaluatorPairExample.h:83-133
-    static bool evalEnergy(Scalar rsq, Scalar rcutsq, const param_type& p, bool energy_shift, Scalar& pair_eng)
-        {
-        if (!(rsq < rcutsq))
-            return false;
-        const Scalar overlap = p.sigma - std::sqrt(rsq);
-        pair_eng = 0.5 * p.k * overlap * overlap;
-        if (energy_shift)
-            {
-            const Scalar co = p.sigma - std::sqrt(rcutsq);
-            pair_eng -= 0.5 * p.k * co * co;
-            }
-        return true;
-        }
-    };
-
-template<class Ev> class PotentialPairGPU : public ForceCompute
-    {
-    public:
-    typedef typename Ev::param_type param_type;
-    enum energyShiftMode
-        {
-        no_shift = 0,
-        shift,
-        xplor
-        };
-    PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<NeighborListGPUBinned> nlist);
-    ~PotentialPairGPU();
-    void setParams(unsigned int typ1, unsigned int typ2, const param_type& p);
-    param_type getParams(unsigned int typ1, unsigned int typ2) const
-        {
-        return m_params[typ2 * m_ntypes + typ1];
-        }
-    void setRcut(unsigned int typ1, unsigned int typ2, Scalar rcut);
-    Scalar getRCut(unsigned int typ1, unsigned int typ2) const
-        {
-        return (*m_r_cut_nlist)[typ2 * m_ntypes + typ1];
-        }
-    void setRon(unsigned int typ1, unsigned int typ2, Scalar ron);
-    Scalar getROn(unsigned int typ1, unsigned int typ2) const;
-    void setShiftMode(energyShiftMode m)
-        {
-        m_shift_mode = m;
-        }
-    energyShiftMode getShiftMode() const
-        {
-        return m_shift_mode;
-        }
-    void setTailCorrectionEnabled(bool e)
-        {
-        m_tail = e;
-        }
-    bool getTailCorrectionEnabled() const
-        {
-        return m_tail;
-        }
-    void setThreadsPerParticle(unsigned int tpp)
-        {
-        m_tpp = tpp;
-        }
-    unsigned int getThreadsPerParticle() const
-        {
-        return m_tpp;
-        }
-    std::shared_ptr<NeighborListGPUBinned> getNeighborList() const
-        {
-        return m_nlist;
-        }
-    //! U = sum over i in tags1, j in tags2 of V_ij (hoomd/md/PotentialPair.h:833-991): a host-side double loop
-    //! over the two sets with the minimum image in the global box, as in the reference
-    Scalar computeEnergyBetweenSets(const std::vector<unsigned int>& tags1, const std::vector<unsigned int>& tags2);
-
-    protected:
-    void computeForces(uint64_t timestep) override;
-    //! part: 0 every particle; 1 the blocks of tiles that see no ghosts; 2 the other blocks
-    bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0,
-                      unsigned int part = 0);
-    bool launchInterior(uint64_t timestep, const unsigned int* d_flag, unsigned int stale);
-    void computeTailCorrection();
-    uint64_t m_spec_tstep = ~0ull; // time step whose force kernel was queued speculatively
-    // Under domain decomposition the tile blocks that see no ghosts are queued before the halo exchange
-    // (which runs on a stream of its own), the other blocks behind it.
-    uint64_t m_interior_tstep = ~0ull; // time step whose interior blocks were queued ahead of the exchange
-    unsigned int m_win_lo[3] = {0, 0, 0}, m_win_hi[3] = {0, 0, 0};
-    std::shared_ptr<NeighborListGPUBinned> m_nlist;
-    unsigned int m_ntypes;
-    energyShiftMode m_shift_mode = no_shift;
-    bool m_tail = false, m_tables_dirty = true;
-    unsigned int m_tpp = 0;
-    std::vector<param_type> m_params;
-    std::vector<Scalar> m_rcutsq, m_ronsq;
-    std::shared_ptr<std::vector<Scalar>> m_r_cut_nlist;
-    DeviceArray<param_type> m_d_params;
-    DeviceArray<Scalar> m_d_rcutsq, m_d_ronsq;
-    };
 
 // ---------------------------------------------------------------------------------------------
 // PotentialBondGPU<EvaluatorBondFENE> (hoomd/md/PotentialBond.h, hoomd/md/PotentialBondGPU.h)
@@ -1576,6 +1422,10 @@ class IntegratorTwoStep
         {
         m_prepared = false;
         }
+    bool isPrepared() const
+        {
+        return m_prepared;
+        }
     //! hoomd/md/IntegratorTwoStep.cc:161-196
     Scalar getTranslationalDOF(std::shared_ptr<ParticleGroup> group);
     void updateGroupDOF(std::shared_ptr<ParticleGroup> group)
@@ -1665,7 +1515,9 @@ class System
         {
         m_pressure_flag = b;
         }
-    void run(uint64_t nsteps);
+    /// `prepare` = false continues a run that was cut into pieces with nothing changed in between (the caller wrote
+    /// output between them): the forced migration and the force computation of a run's start are not repeated
+    void run(uint64_t nsteps, bool prepare = true);
     uint64_t getCurrentTimeStep() const
         {
         return m_cur_tstep;

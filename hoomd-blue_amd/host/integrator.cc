@@ -342,13 +342,14 @@ void ParticleSorter::sortNow()
 
 // ---------------------------------------------------------------------------------------------
 // hoomd/System.cc:80-190
-void System::run(uint64_t nsteps)
+void System::run(uint64_t nsteps, bool prepare)
     {
     if (!m_integrator)
         throw std::runtime_error("Cannot run without an integrator");
     auto pdata = m_sysdef->getParticleData();
     pdata->setFlags(m_pressure_flag ? (1u << pressure_tensor) : 0u);
-    m_integrator->prepRun(m_cur_tstep);
+    if (prepare || !m_integrator->isPrepared())
+        m_integrator->prepRun(m_cur_tstep);
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t s = 0; s < nsteps; s++)

@@ -10,6 +10,9 @@
 
 #include "hoomd_host.h"
 
+#include "hoomd/md/EvaluatorPairLJ.h"
+#include "hoomd/md/PotentialPairGPU.h"
+
 namespace py = pybind11;
 using namespace hoomd_amd;
 
@@ -127,25 +130,6 @@ class PyCommunicator : public Communicator
         }
     };
 
-template<class Ev, class P2D, class D2P> void export_pair(py::module& m, const char* name, P2D params_to_dict, D2P dict_to_params)
-    {
-    typedef PotentialPairGPU<Ev> T;
-    py::class_<T, ForceCompute, std::shared_ptr<T>>(m, name)
-        .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<NeighborListGPUBinned>>())
-        .def("setParams", [dict_to_params](T& self, py::tuple types, py::dict v)
-             { self.setParams(types[0].cast<unsigned int>(), types[1].cast<unsigned int>(), dict_to_params(v)); })
-        .def("getParams", [params_to_dict](T& self, py::tuple types)
-             { return params_to_dict(self.getParams(types[0].cast<unsigned int>(), types[1].cast<unsigned int>())); })
-        .def("setRCut", [](T& self, py::tuple types, Scalar r) { self.setRcut(types[0].cast<unsigned int>(), types[1].cast<unsigned int>(), r); })
-        .def("getRCut", [](T& self, py::tuple types) { return self.getRCut(types[0].cast<unsigned int>(), types[1].cast<unsigned int>()); })
-        .def("setROn", [](T& self, py::tuple types, Scalar r) { self.setRon(types[0].cast<unsigned int>(), types[1].cast<unsigned int>(), r); })
-        .def("getROn", [](T& self, py::tuple types) { return self.getROn(types[0].cast<unsigned int>(), types[1].cast<unsigned int>()); })
-        .def_property("mode", [](T& self) { return (int)self.getShiftMode(); },
-                      [](T& self, int mode) { self.setShiftMode((typename T::energyShiftMode)mode); })
-        .def_property("tail_correction", &T::getTailCorrectionEnabled, &T::setTailCorrectionEnabled)
-        .def("computeEnergyBetweenSets", &T::computeEnergyBetweenSets)
-        .def_property("threads_per_particle", &T::getThreadsPerParticle, &T::setThreadsPerParticle);
-    }
     } // namespace
 
 PYBIND11_MODULE(_hoomd_amd, m)
@@ -431,40 +415,9 @@ PYBIND11_MODULE(_hoomd_amd, m)
              return v;
              });
 
-    export_pair<EvaluatorLJHost>(
-        m, "PotentialPairLJGPU",
-        [](const hmd_lj_params_t& p)
-        {
-        py::dict v;
-        v["sigma"] = std::pow(p.sigma_6, 1. / 6.);
-        v["epsilon"] = p.epsilon_x_4 / 4.0;
-        return v;
-        },
-        [](py::dict v)
-        {
-        // hoomd/md/EvaluatorPairLJ.h:119-133
-        const Scalar sigma = v["sigma"].cast<Scalar>(), epsilon = v["epsilon"].cast<Scalar>();
-        hmd_lj_params_t p;
-        p.sigma_6 = sigma * sigma * sigma * sigma * sigma * sigma;
-        p.epsilon_x_4 = Scalar(4.0) * epsilon;
-        return p;
-        });
-    export_pair<EvaluatorExampleHost>(
-        m, "PotentialPairExampleGPU",
-        [](const hmd_example_params_t& p)
-        {
-        py::dict v;
-        v["k"] = p.k;
-        v["sigma"] = p.sigma;
-        return v;
-        },
-        [](py::dict v)
-        {
-        hmd_example_params_t p;
-        p.k = v["k"].cast<Scalar>();
-        p.sigma = v["sigma"].cast<Scalar>();
-        return p;
-        });
+    // pair potentials: one export line per class, as a plugin's module has (example_plugins/pair_plugin/module.cc:20-26)
+    hoomd::md::detail::export_PotentialPair<hoomd::md::EvaluatorPairLJ>(m, "PotentialPairLJ");
+    hoomd::md::detail::export_PotentialPairGPU<hoomd::md::EvaluatorPairLJ>(m, "PotentialPairLJGPU");
 
     py::class_<ComputeThermoGPU, std::shared_ptr<ComputeThermoGPU>>(m, "ComputeThermoGPU")
         .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<ParticleGroup>>())
@@ -542,7 +495,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("setIntegrator", &System::setIntegrator)
         .def("setSorter", &System::setSorter)
         .def("setPressureFlag", &System::setPressureFlag)
-        .def("run", &System::run, py::call_guard<py::gil_scoped_release>())
+        .def("run", &System::run, py::arg("nsteps"), py::arg("prepare") = true, py::call_guard<py::gil_scoped_release>())
         .def("getCurrentTimeStep", &System::getCurrentTimeStep)
         .def("getLastTPS", &System::getLastTPS)
         .def("getLastWalltime", &System::getLastWalltime);

@@ -26,11 +26,9 @@ def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, 
     # one case starts with migration messages of a single row: the headers tell every rank that it was not
     # enough, and all of them send again with room for the largest message
     env = dict(os.environ, HOOMD_AMD_MIGRATE_SLOT_ROWS="1") if world == 4 and not overlap else None
-    # Ranks that share a GPU keep the exchange stream at normal priority (chosen by the communicator: with more
-    # processes than hardware queues a high-priority queue waiting on a normal-priority one starves it).  Two
-    # processes do not oversubscribe the queues, so that case runs at the production (high) priority.
-    if world == 2 and overlap:
-        env = dict(os.environ, HOOMD_AMD_COMM_PRIORITY="high")
+    # Ranks that share a GPU keep the exchange stream at normal priority (chosen by the communicator: a high-priority
+    # queue of one process that waits on a normal-priority queue can keep the queues of the other processes off the
+    # hardware, two processes are enough for that).  The production priority runs in the one-rank test below.
     launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter], timeout=60, env=env)
     a, b = np.load(ref), np.load(out)
     assert sum(b["N_local"]) == n[0] * n[1] * n[2] and all(g > 0 for g in b["n_ghosts"])
@@ -76,3 +74,20 @@ def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, 
     assert np.allclose(o.energies(), b["e1"], rtol=1e-7)
     if not sorter:
         assert o.stats()["num_builds"] == b["builds"][0]
+
+
+def test_one_rank_decomposition_over_rccl_at_production_priority():
+    """The production transport and stream priority, as far as one GPU allows: one rank (nothing to exchange: the
+    migration, ghost and vote collectives run empty), RCCL collectives on the high-priority exchange stream."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dd", "--lattice", "40x40x40", "--equil", "400",
+                        "--warmup", "20", "--steps", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=140,
+                       env=dict(os.environ, MASTER_PORT="29533"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    d = out["config"]["decomposition"]
+    assert d["backend"] == "nccl" and d["exchange_stream_high_priority"] is True
+    assert out["config"]["rebuilds_in_timed_region"] > 10 and 60 < out["config"]["mean_listed_neighbors"] < 110
+    assert out["value"] > 0

@@ -1,0 +1,140 @@
+"""The pair-potential plugin contract (example_plugins/pair_plugin of the reference: EvaluatorPairExample.h:33-167,
+PotentialPairExampleGPUKernel.cu:13-15, module.cc:20-26): ONE evaluator header read by both compilers, one HIP
+translation unit naming the kernel instantiation, one module file with two export lines, built outside the framework's
+tree.  Without a GPU: a renamed copy of the example with a different potential builds from a directory outside the
+repository and exports what it should.  With a GPU: the installed example plugin against the CPU oracle on a liquid."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PLUGIN = os.path.join(ROOT, "example_plugins", "pair_plugin")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hoomd-blue_amd"), os.path.join(ROOT, "scripts")]
+
+QUARTIC = """
+    DEVICE bool evalForceAndEnergy(Scalar& force_divr, Scalar& pair_eng, bool energy_shift)
+        {
+        if (!(rsq < rcutsq))
+            return false;
+        const Scalar r = fast::sqrt(rsq);
+        const Scalar stretch = sigma - r;
+        force_divr = Scalar(4.0) * k * stretch * stretch * stretch / r;
+        pair_eng = k * stretch * stretch * stretch * stretch;
+        return true;
+        }
+"""
+
+
+def _nm(path):
+    return subprocess.run(["nm", "-D", "--demangle", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+
+
+def test_core_and_plugin_export_their_kernel_instantiations():
+    core = _nm(os.path.join(ROOT, "hoomd-blue_amd", "libhoomd_amd.so"))
+    assert "hoomd::md::kernel::gpu_compute_pair_forces<hoomd::md::EvaluatorPairLJ>" in core
+    plug = os.path.join(ROOT, "hoomd-blue_amd", "hoomd_amd", "pair_plugin")
+    so = [f for f in os.listdir(plug) if f.startswith("_pair_plugin") and f.endswith(".so")]
+    assert so, "example plugin not installed (make -C example_plugins/pair_plugin install)"
+    syms = _nm(os.path.join(plug, so[0]))
+    assert "hoomd::md::kernel::gpu_compute_pair_forces<hoomd::md::EvaluatorPairExample>" in syms
+    assert "PyInit__pair_plugin" in syms
+    # the plugin carries its own kernels and its own instantiation of the host classes, nothing of the core's
+    assert "EvaluatorPairLJ" not in syms
+
+
+def test_plugin_module_classes():
+    import hoomd_amd
+    from hoomd_amd import pair_plugin
+    cpp = hoomd_amd._hoomd_amd
+    m = pair_plugin.pair._pair_plugin
+    assert issubclass(m.PotentialPairExampleGPU, m.PotentialPairExample) and issubclass(m.PotentialPairExample, cpp.ForceCompute)
+    assert issubclass(cpp.PotentialPairLJGPU, cpp.PotentialPairLJ) and issubclass(cpp.PotentialPairLJ, cpp.ForceCompute)
+    for name in ("setParams", "getParams", "setRCut", "getRCut", "setROn", "getROn", "mode", "tail_correction", "computeEnergyBetweenSets"):
+        assert hasattr(m.PotentialPairExample, name) and hasattr(cpp.PotentialPairLJ, name)
+    assert pair_plugin.pair.ExamplePair._ext_module is m
+
+
+def test_a_new_plugin_builds_outside_the_tree(tmp_path):
+    """Copy the example to a directory outside the repository, give it another name and another potential
+    (V = k (sigma - r)^4) by editing the ONE header, and build it with the example's Makefile against this checkout."""
+    work = tmp_path / "quartic_plugin"
+    work.mkdir()
+    for f in ("EvaluatorPairExample.h", "PotentialPairExampleGPUKernel.hip", "module.cc", "Makefile", "__init__.py", "pair.py"):
+        shutil.copy(os.path.join(PLUGIN, f), work / f)
+    hdr = (work / "EvaluatorPairExample.h").read_text()
+    a = hdr.index("    DEVICE bool evalForceAndEnergy")
+    b = hdr.index("    // a potential that ends at its cutoff")
+    hdr = hdr[:a] + QUARTIC.lstrip("\n") + "\n" + hdr[b:]
+    hdr = hdr.replace("EvaluatorPairExample", "EvaluatorPairQuartic").replace('"example_pair"', '"quartic_pair"')
+    (work / "EvaluatorPairQuartic.h").write_text(hdr)
+    os.remove(work / "EvaluatorPairExample.h")
+    for f in ("PotentialPairExampleGPUKernel.hip", "module.cc"):
+        t = (work / f).read_text().replace("EvaluatorPairExample", "EvaluatorPairQuartic").replace("_pair_plugin", "_quartic_plugin")
+        t = t.replace("PotentialPairExample", "PotentialPairQuartic")
+        (work / f).write_text(t)
+    r = subprocess.run(["make", "-s", "-C", str(work), f"HOOMD_AMD_ROOT={ROOT}", "NAME=quartic_plugin"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    so = [f for f in os.listdir(work) if f.startswith("_quartic_plugin") and f.endswith(".so")]
+    assert len(so) == 1
+    syms = _nm(str(work / so[0]))
+    assert "hoomd::md::kernel::gpu_compute_pair_forces<hoomd::md::EvaluatorPairQuartic>" in syms and "PyInit__quartic_plugin" in syms
+    # loads next to the core module and registers its classes under the core's base class (no GPU needed for that)
+    code = ("import sys, importlib.util; sys.path[:0] = [%r]; import hoomd_amd\n"
+            "spec = importlib.util.spec_from_file_location('_quartic_plugin', %r); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+            "assert issubclass(m.PotentialPairQuarticGPU, m.PotentialPairQuartic) and issubclass(m.PotentialPairQuartic, hoomd_amd._hoomd_amd.ForceCompute)\n"
+            "print('ok')" % (os.path.join(ROOT, "hoomd-blue_amd"), str(work / so[0])))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,shift", [("none", 0), ("shift", 1), ("xplor", 2)])
+def test_example_plugin_on_a_liquid_matches_the_oracle(mode, shift):
+    """The plugin's kernels (tile path: the box has more than three cells a side) and the host pass of the same header
+    (pair energies between two sets) against the CPU oracle's evaluator, 1e-6 relative."""
+    import hoomd_amd as hoomd
+    import lj_liquid
+    from hoomd_amd import pair_plugin
+    from oracle import oracle as orc
+    snap = lj_liquid.make_snapshot(hoomd, 14, rho=1.0, kT=1.0, seed=5)
+    rng = np.random.default_rng(6)
+    snap.particles.position[:] += rng.normal(0, 0.12, snap.particles.position.shape)
+    snap.wrap()
+    N = snap.particles.N
+    sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=1)
+    sim.create_state_from_snapshot(snap)
+    cell = hoomd.md.nlist.Cell(buffer=0.3)
+    ex = pair_plugin.pair.ExamplePair(cell, default_r_cut=1.6, default_r_on=1.2, mode=mode)
+    ex.params[("A", "A")] = dict(k=30.0, sigma=1.2)
+    sim.operations.integrator = hoomd.md.Integrator(dt=0.001, methods=[hoomd.md.methods.ConstantVolume(hoomd.filter.All())], forces=[ex])
+    sim.run(0)
+    assert cell._cpp_obj.tiles_active
+    pos = orc.pack_pos(snap.particles.position, snap.particles.typeid)
+    obox = orc.Box.from_L(*snap.configuration.box[:3])
+    ref = orc.nlist_binned(pos, N, obox, [[1.6]], 0.3, storage_full=True)
+    F_ref, _ = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(30.0, 1.2)], [[1.6 ** 2]], [[1.2 ** 2]],
+                               shift_mode=shift, compute_virial=False)
+    assert np.abs(ex.forces - F_ref[:, :3]).max() / np.abs(F_ref[:, :3]).max() < 1e-6
+    assert np.abs(ex.energies - F_ref[:, 3]).max() / np.abs(F_ref[:, 3]).max() < 1e-6
+    # host pass of the same header: pair energy between the even and the odd tags, against a plain NumPy double loop
+    even, odd = np.arange(0, N, 2), np.arange(1, N, 2)
+    x, L = snap.particles.position, np.asarray(snap.configuration.box[:3])
+    d = x[even][:, None, :] - x[odd][None, :, :]
+    d -= L * np.rint(d / L)
+    r2 = np.einsum("ijk,ijk->ij", d, d)
+    r = np.sqrt(r2)
+    e = np.where(r2 < 1.6 ** 2, 0.5 * 30.0 * (1.2 - r) ** 2, 0.0)
+    if mode == "shift":
+        e -= np.where(r2 < 1.6 ** 2, 0.5 * 30.0 * (1.2 - 1.6) ** 2, 0.0)
+    elif mode == "xplor":
+        rc2, ro2 = 1.6 ** 2, 1.2 ** 2
+        sw = (rc2 - r2) ** 2 * (rc2 + 2 * r2 - 3 * ro2) / (rc2 - ro2) ** 3
+        e *= np.where(r2 >= ro2, sw, 1.0)
+    assert abs(ex.compute_energy(even, odd) - e.sum()) / abs(e.sum()) < 1e-10
+    with pytest.raises(Exception):
+        ex.params[("A", "A")] = dict(k=1.0)
