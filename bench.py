@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--time-all", action="store_true", help="time every kernel family with HIP events (perturbs the run) and print the table to stderr")
     ap.add_argument("--cprofile", action="store_true", help="profile the host side of the timed region (rank 0, to stderr)")
     ap.add_argument("--force-dd", action="store_true", help="run the domain-decomposition code path even on one rank (rehearsal of the RCCL calls)")
+    ap.add_argument("--no-tiles", action="store_true", help="force the neighbor list to index rows (the tile path is chosen by cell occupancy otherwise)")
     ap.add_argument("--no-overlap", action="store_true", help="domain decomposition: do not compute interior blocks during the halo exchange")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
@@ -176,6 +177,9 @@ def main():
     if args.no_overlap:
         sim.run(0)
         cell._cpp_obj.overlap = False
+    if args.no_tiles:
+        cell._attach(sim) if cell._cpp_obj is None else None
+        cell._cpp_obj.tiles = False
     if args.tpp:
         sim.run(0)
         lj._cpp_obj.threads_per_particle = args.tpp

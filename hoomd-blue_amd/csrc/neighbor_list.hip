@@ -48,6 +48,14 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
     }
 
+// exclusions by particle index, applied while rows are built (d_n_ex == nullptr: none)
+struct nl_excl_t
+    {
+    const unsigned int* d_n_ex;
+    const unsigned int* d_ex_list;
+    hmd_index2d_t exli;
+    };
+
 // MODE 0: minimum image per pair (any box); 1: the same for orthorhombic boxes; 2: the periodic image
 // of every adjacent cell is fixed up front (possible when each periodic direction has at least three
 // cells: the 3x3x3 stencil then never holds two images of one cell), so candidates are shifted once
@@ -58,7 +66,8 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 template<bool SINGLE_TYPE, bool FILTER_BODY, int MODE, bool TILE>
 __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) nlist_binned_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc,
                                                                 unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
-                                                                unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group, unsigned int row_pieces)
+                                                                unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group, unsigned int row_pieces,
+                                                                nl_excl_t ex)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // per wave: 64 exclusive offsets + 64 adjacent cell ids; then the ntypes^2 r_list^2 table
@@ -316,6 +325,16 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
                     nmax_w = min(nmax_i, tile_row_cap);
                     }
+                // excluded partners of this particle: the first four in registers, longer lists read again per slab
+                unsigned int nex_i = 0, ex_r[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                if (ex.d_n_ex)
+                    {
+                    nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
+#pragma unroll
+                    for (unsigned int o = 0; o < 4; o++)
+                        if (o < nex_i)
+                            ex_r[o] = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+                    }
 
 #pragma unroll
                 for (int c = 0; c < NL_MAXK; c++)
@@ -332,6 +351,12 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         bool hit = (rsq <= rl2) && (cj[c] != i_idx);
                         if (FILTER_BODY)
                             hit = hit && !(body_i != HMD_NO_BODY && body_i == cb[c]);
+                        if (nex_i)
+                            {
+                            hit = hit && cj[c] != ex_r[0] && cj[c] != ex_r[1] && cj[c] != ex_r[2] && cj[c] != ex_r[3];
+                            for (unsigned int o = 4; o < nex_i; o++)
+                                hit = hit && cj[c] != ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)];
+                            }
                         const unsigned long long mask = __ballot(hit);
                         if (mask)
                             {
@@ -454,11 +479,11 @@ __device__ __forceinline__ nl_pref_t nl_pref_thresholds(double rl, double rl2, d
     return t;
     }
 
-template<bool TILE>
+template<bool TILE, bool EXCL>
 __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
                                                               unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
                                                               unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group,
-                                                              unsigned int row_pieces)
+                                                              unsigned int row_pieces, nl_excl_t ex)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
     unsigned int* s_excl_all = reinterpret_cast<unsigned int*>(s_raw);
@@ -622,6 +647,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(NL_MAXK * 64)));
             nl_v2f fx[NL_PAIRS], fy[NL_PAIRS], fz[NL_PAIRS];
             unsigned int co[NL_MAXK]; // what a row stores for the candidate: tile slot or particle index
+            unsigned int cidx[(EXCL && TILE) ? NL_MAXK : 1]; // tile rows with exclusions: the candidate's particle index as well
             // Loads in two batches of six slabs: first every address of a batch (the searches run on LDS), then every
             // load, then the conversions -- two memory round trips per pass instead of one per slab.
             constexpr int NL_BATCH = NL_MAXK / 2;
@@ -634,6 +660,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     for (int c = b0; c < b0 + NL_BATCH; c++)
                         {
                         co[c] = 0xffffffffu;
+                        if (EXCL && TILE)
+                            cidx[c] = 0xffffffffu;
                         if (c & 1)
                             fx[c / 2].y = fy[c / 2].y = fz[c / 2].y = 1.0e18f;
                         else
@@ -668,6 +696,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     // below would take a NaN with its sign set for a hit)
                     float x32 = 1.0e18f, y32 = x32, z32 = x32;
                     co[c] = 0xffffffffu;
+                    if (EXCL && TILE)
+                        cidx[c] = w_[q] != 0xffffffffu ? hmd_double_as_uint(vzw[q].y) : 0xffffffffu;
                     if (w_[q] != 0xffffffffu)
                         {
                         const unsigned int lo = lo_[q];
@@ -766,6 +796,19 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 const unsigned int k_self = self_first + hbase + iu - pbase; // (wraps below pbase: then >= NL_MAXK * 64)
                 if ((k_self >> 6) < nslab && lane == (k_self & 63u))
                     bits &= ~(1u << (nslab - 1u - (k_self >> 6)));
+                // excluded partners, by particle index
+                if (EXCL)
+                    {
+                    const unsigned int nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
+                    for (unsigned int o = 0; o < nex_i; o++)
+                        {
+                        const unsigned int e = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+#pragma unroll
+                        for (int c = 0; c < NL_MAXK; c++)
+                            if ((unsigned int)(c * 64) < Tp && (TILE ? cidx[c] : co[c]) == e)
+                                bits &= ~(1u << (nslab - 1u - (unsigned int)c));
+                        }
+                    }
 
                 // ---- compaction: hits ordered by lane, then slab.  One scan over the wave places every lane's hits. ----
                 const unsigned int mine = (unsigned int)__popc(bits);
@@ -1146,8 +1189,10 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
 template<bool ST, bool FB>
 int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
                  unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr,
-                 unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr, const unsigned int* d_block_group = nullptr, unsigned int row_pieces = 0)
+                 unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr, const unsigned int* d_block_group = nullptr, unsigned int row_pieces = 0,
+                 nl_excl_t ex = nl_excl_t {nullptr, nullptr, hmd_index2d_t {0, 0}})
     {
+    const nl_excl_t no_ex = {nullptr, nullptr, hmd_index2d_t {0, 0}};
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const dim3 grid(hmd_div_up(ncells, cells_per_block));
     // fixed images need a radius-1 stencil in 3D whose cells are distinct along every periodic direction
@@ -1164,31 +1209,37 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
         for (int d = 0; d < 3; d++)
             wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
         const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF) + sizeof(double) * 3 * 64) * NL_WAVES;
-        if (d_tile)
-            hipLaunchKernelGGL((nlist_pref_kernel<true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
-                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        if (d_tile && ex.d_n_ex)
+            hipLaunchKernelGGL((nlist_pref_kernel<true, true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
+                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+        else if (d_tile)
+            hipLaunchKernelGGL((nlist_pref_kernel<true, false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
+                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, no_ex);
+        else if (ex.d_n_ex)
+            hipLaunchKernelGGL((nlist_pref_kernel<false, true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 0u, ex);
         else
-            hipLaunchKernelGGL((nlist_pref_kernel<false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, 0u);
+            hipLaunchKernelGGL((nlist_pref_kernel<false, false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 0u, no_ex);
         return hmd_launch_status();
         }
     if (d_tile)
         {
         HMD_REQUIRE(fixed_images, HMD_ERR_UNSUPPORTED, "tile rows need a 27-cell stencil with at least 3 cells along every periodic direction");
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, true>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
         }
     else if (fixed_images)
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 2, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
     else if (hmd_box_is_ortho(a.box))
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 1, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
     else
-        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u);
+        hipLaunchKernelGGL((nlist_binned_kernel<ST, FB, 0, false>), grid, dim3(NL_BLOCK), lds, s, a, ncells, wpc, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
     return hmd_launch_status();
     }
 
 int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigned short* d_tile, unsigned int tile_capacity, unsigned int* d_tile_overflow,
                         hmd_uint4* d_slot_meta, unsigned int* d_slot_of = nullptr, hmd_scalar4* d_cpos = nullptr, const unsigned int* d_block_group = nullptr,
-                        unsigned int row_pieces = 0)
+                        unsigned int row_pieces = 0, nl_excl_t ex = nl_excl_t {nullptr, nullptr, hmd_index2d_t {0, 0}})
     {
     const bool single = (a.ntypes == 1);
     const bool fb = a.filter_body != 0;
@@ -1201,12 +1252,12 @@ int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigne
         wpc = 4;
     const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
     if (single && !fb)
-        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
     if (single && fb)
-        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        return launch_nlist<true, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
     if (!single && !fb)
-        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
-    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces);
+        return launch_nlist<false, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+    return launch_nlist<false, true>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
     }
     } // namespace
 
@@ -1233,7 +1284,10 @@ extern "C" int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, voi
     if (a.N == 0)
         return HMD_OK;
 
-    return nlist_binned_driver(a, (hipStream_t)stream, nullptr, 0u, nullptr, nullptr);
+    HMD_REQUIRE(!a.d_n_ex_idx || (a.d_ex_list_idx && a.exli.w >= a.N), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_binned: exclusions need d_ex_list_idx and an indexer at least N wide");
+    const nl_excl_t ex = {a.d_n_ex_idx, a.d_ex_list_idx, a.exli};
+    return nlist_binned_driver(a, (hipStream_t)stream, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
     }
 
 // Tile rows from the same kernel (declared with the tile path in the header).
@@ -1288,8 +1342,11 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     const bool bg_cached = bg_lds <= 60 * 1024;
     hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), bg_cached ? bg_lds : 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci,
                        t.geom.cli.w, const_cast<unsigned int*>(t.geom.d_block_group), tile_groups, t.d_tile_overflow, bg_cached);
+    HMD_REQUIRE(!t.d_n_ex_idx || (t.d_ex_list_idx && t.exli.w >= t.N), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_compute_nlist_tiles: exclusions need d_ex_list_idx and an indexer at least N wide");
+    const nl_excl_t ex = {t.d_n_ex_idx, t.d_ex_list_idx, t.exli};
     return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta, t.d_slot_of,
-                               t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr, t.geom.d_block_group, t.geom.row_pieces);
+                               t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr, t.geom.d_block_group, t.geom.row_pieces, ex);
     }
 
 extern "C" size_t hmd_nlist_tiles_storage_entries(const hmd_index3d_t* ci, unsigned int n_members, unsigned int row_pieces)

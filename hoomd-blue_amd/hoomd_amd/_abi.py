@@ -91,7 +91,7 @@ class NlistBinnedArgs(C.Structure):
                 ("d_cell_xyzf", vp), ("d_cell_idx", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp),
                 ("ci", Index3D), ("cli", Index2D), ("cadji", Index2D), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
                 ("ntypes", u32), ("threads_per_particle", u32), ("block_size", u32), ("filter_body", C.c_int),
-                ("ghost_width", Scalar3)]
+                ("ghost_width", Scalar3), ("d_n_ex_idx", vp), ("d_ex_list_idx", vp), ("exli", Index2D)]
 
 
 class NlistFilterArgs(C.Structure):
@@ -233,7 +233,8 @@ class NlistTilesArgs(C.Structure):
     _fields_ = [("geom", TileGeom), ("d_cell_xyzf", vp), ("d_cell_type_body", vp), ("d_cell_adj", vp), ("cadji", Index2D),
                 ("d_tile_nlist", vp), ("d_slot_meta", vp), ("d_slot_of", vp), ("d_n_neigh", vp), ("d_last_updated_pos", vp), ("d_conditions", vp),
                 ("d_Nmax", vp), ("d_head_list", vp), ("d_pos", vp), ("N", u32), ("box", Box), ("d_r_cut", vp), ("r_buff", f64),
-                ("ntypes", u32), ("d_tile_overflow", vp), ("tile_nlist_entries", C.c_size_t)]
+                ("ntypes", u32), ("d_tile_overflow", vp), ("tile_nlist_entries", C.c_size_t), ("d_n_ex_idx", vp), ("d_ex_list_idx", vp),
+                ("exli", Index2D)]
 
 
 class TilesToRowsArgs(C.Structure):

@@ -97,7 +97,7 @@ def build_head_list(pos, N, Nmax_t):
     return head, int(req.item())
 
 
-def nlist_binned(pos, N, box, r_cut, r_buff, cl, adj, n_ghost=0, ghost_width=(0, 0, 0), body=None, filter_body=False):
+def nlist_binned(pos, N, box, r_cut, r_buff, cl, adj, n_ghost=0, ghost_width=(0, 0, 0), body=None, filter_body=False, exclusions=None):
     """Full protocol: head list -> build -> grow Nmax on overflow -> rebuild
     (hoomd/md/NeighborList.cc:406-434).  ``cl`` from compute_cell_list, ``adj`` (ncells, n_adj) int32."""
     dev = pos.device
@@ -123,6 +123,9 @@ def nlist_binned(pos, N, box, r_cut, r_buff, cl, adj, n_ghost=0, ghost_width=(0,
         a.d_r_cut, a.r_buff, a.ntypes = ptr(r_cut_t), float(r_buff), nt
         a.filter_body = int(filter_body)
         a.ghost_width = _s3(ghost_width)
+        if exclusions is not None:  # (n_ex, ex_list) by particle index, ex_list of shape (height, pitch)
+            a.d_n_ex_idx, a.d_ex_list_idx = ptr(exclusions[0]), ptr(exclusions[1])
+            a.exli = Index2D(exclusions[1].shape[1], exclusions[1].shape[0])
         check(_abi.lib.hmd_compute_nlist_binned(C.byref(a), _stream(pos)), "hmd_compute_nlist_binned")
         n_builds += 1
         c = cond.cpu().numpy().astype(np.int64)
@@ -193,8 +196,9 @@ def tile_geom(cl, box, ntypes=1, capacity=None):
     return g
 
 
-def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
-    """Tile build with the head-list / overflow protocol of nlist_binned."""
+def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None, exclusions=None):
+    """Tile build with the head-list / overflow protocol of nlist_binned.  exclusions: (n_ex, ex_list) by particle
+    index, ex_list of shape (height, pitch) with pitch >= N: left out of the rows as they are built."""
     dev = pos.device
     r_cut_t = torch.as_tensor(np.asarray(r_cut, dtype=np.float64), device=dev).contiguous()
     nt = r_cut_t.shape[0]
@@ -225,6 +229,9 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None):
         a.d_Nmax, a.d_head_list, a.d_pos, a.N, a.box = ptr(Nmax_t), ptr(head), ptr(pos), N, box
         a.d_r_cut, a.r_buff, a.ntypes, a.d_tile_overflow = ptr(r_cut_t), float(r_buff), nt, ptr(overflow)
         a.tile_nlist_entries = entries
+        if exclusions is not None:
+            a.d_n_ex_idx, a.d_ex_list_idx = ptr(exclusions[0]), ptr(exclusions[1])
+            a.exli = Index2D(exclusions[1].shape[1], exclusions[1].shape[0])
         check(_abi.lib.hmd_compute_nlist_tiles(C.byref(a), _stream(pos)), "hmd_compute_nlist_tiles")
         n_builds += 1
         if int(overflow[0].item()):

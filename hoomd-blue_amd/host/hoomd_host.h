@@ -957,6 +957,15 @@ class NeighborListGPUBinned : public Compute
         {
         return m_tile_capacity;
         }
+    void setTileMinOccupancy(double v)
+        {
+        m_tile_min_occupancy = v;
+        forceUpdate();
+        }
+    double getTileMinOccupancy() const
+        {
+        return m_tile_min_occupancy;
+        }
     void setTilesEnabled(bool b)
         {
         m_tiles_enabled = b;
@@ -1064,7 +1073,6 @@ class NeighborListGPUBinned : public Compute
     void resetConditions();
     void resizeNlist(size_t size);
     void updateExListIdx();
-    void filterNlist();
     void reallocatePerParticle();
     void ensureRows();
     bool tilesUsable(unsigned int& capacity);
@@ -1116,6 +1124,7 @@ class NeighborListGPUBinned : public Compute
 
     // tile rows
     bool m_tiles_enabled = true, m_tiles_active = false, m_rows_valid = true, m_tiles_overflowed = false;
+    double m_tile_min_occupancy = 8.0; // particles per cell from which the tile path is used
     unsigned int m_tile_capacity = 0;
     DeviceArray<unsigned short> m_tile_nlist;
     DeviceArray<unsigned int> m_block_group; // first group of rows of every block of 2x2x2 cells
@@ -1602,6 +1611,22 @@ struct ScopedKernelTimer
             KernelTimer::get().end(n);
         }
     };
+
+// A plugin built outside the tree holds the layout of the classes above in its own objects (their inline accessors,
+// the offsets of the members its templates touch).  Sizes of the classes a pair potential reaches into, folded into
+// one number: the plugin computes it from the headers it was compiled with, the core module from its own, and the
+// export functions refuse to register a plugin whose number differs (rebuild the plugin against this installation).
+inline unsigned long long hostLayoutFingerprintOfTheseHeaders()
+    {
+    unsigned long long h = 1469598103934665603ull;
+    const size_t sizes[] = {sizeof(ParticleData), sizeof(SystemDefinition), sizeof(Compute), sizeof(CellListGPU), sizeof(NeighborListGPUBinned),
+                            sizeof(ForceCompute), sizeof(BoxDim), sizeof(KernelTimer), sizeof(hmd_pair_args_t), sizeof(hmd_tile_geom_t)};
+    for (size_t v : sizes)
+        h = (h ^ (unsigned long long)v) * 1099511628211ull;
+    return h;
+    }
+//! the same number as the core module was compiled with (defined in particle_data.cc)
+unsigned long long hostLayoutFingerprint();
 
     } // namespace hoomd_amd
 

@@ -318,6 +318,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("deterministic", &NeighborListGPUBinned::getDeterministic, &NeighborListGPUBinned::setDeterministic)
         .def_property_readonly("num_builds", &NeighborListGPUBinned::getNumUpdates)
         .def_property("tiles", &NeighborListGPUBinned::getTilesEnabled, &NeighborListGPUBinned::setTilesEnabled)
+        .def_property("tile_min_occupancy", &NeighborListGPUBinned::getTileMinOccupancy, &NeighborListGPUBinned::setTileMinOccupancy)
         .def_property_readonly("tiles_active", &NeighborListGPUBinned::tilesActive)
         .def_property_readonly("tile_capacity", &NeighborListGPUBinned::getTileCapacity)
         .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)

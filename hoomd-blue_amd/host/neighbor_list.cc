@@ -506,6 +506,13 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         a.ntypes = m_pdata->getNTypes();
         a.d_tile_overflow = m_conditions.get() + a.ntypes;
         a.tile_nlist_entries = m_tile_nlist.size();
+        if (m_exclusions_set)
+            {
+            // left out while the rows are written: no filter pass over tile rows (hoomd/md/NeighborListGPU.cu:158-223)
+            a.d_n_ex_idx = m_n_ex_idx.get();
+            a.d_ex_list_idx = m_ex_list_idx.get();
+            a.exli = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
+            }
         hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
         abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
         m_cpos_tstep = timestep; // current for every particle, ghosts included
@@ -540,6 +547,12 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
     a.ntypes = m_pdata->getNTypes();
     a.filter_body = m_filter_body;
     a.ghost_width = m_cl->getGhostWidth();
+    if (m_exclusions_set)
+        {
+        a.d_n_ex_idx = m_n_ex_idx.get();
+        a.d_ex_list_idx = m_ex_list_idx.get();
+        a.exli = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
+        }
     abiCheck(hmd_compute_nlist_binned(&a, nullptr), "hmd_compute_nlist_binned");
     }
 
@@ -611,14 +624,21 @@ void NeighborListGPUBinned::refreshTilePositions()
     abiCheck(hmd_tile_refresh(m_pdata->pos() + first, m_slot_of.get() + first, m_cpos.get(), N + ng - first, nullptr), "hmd_tile_refresh");
     }
 
-// can this build write tile rows?  (no row filters, 3D, grid and occupancy within the tile limits)
+// can this build write tile rows?  (no body filter, 3D, grid and occupancy within the tile limits; exclusions are
+// applied by the build itself)
 bool NeighborListGPUBinned::tilesUsable(unsigned int& capacity)
     {
-    if (!m_tiles_enabled || m_tiles_overflowed || m_filter_body || m_exclusions_set || m_sysdef->getNDimensions() != 3)
+    if (!m_tiles_enabled || m_tiles_overflowed || m_filter_body || m_sysdef->getNDimensions() != 3)
         return false;
     const hmd_index3d_t ci = m_cl->getCellIndexer();
     const hmd_index2d_t cadji = m_cl->getCellAdjIndexer();
     if (cadji.w != 27)
+        return false;
+    // Tiles stage the 64 cells around a block of 8 to serve the block's particles: that pays when cells are well
+    // filled (LJ liquid, r_list 2.9: 20 per cell, tile force 137 us against 320 us from index rows at N = 2^20) and
+    // loses when they are nearly empty (bead-spring melt, r_list 1.52: 3.3 per cell, 244 us against 62 us).
+    const double occupancy = double(m_pdata->getN() + m_pdata->getNGhosts()) / (double(ci.w) * ci.h * ci.d);
+    if (occupancy < m_tile_min_occupancy)
         return false;
     const hmd_box_t box = m_pdata->getBox().b;
     return hmd_nlist_tiles_supported(&ci, &box, m_cl->getNmax(), m_pdata->getNTypes(), &capacity) == HMD_OK;
@@ -684,8 +704,7 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
                 }
             } while (overflowed);
 
-        if (m_exclusions_set)
-            filterNlist();
+        // (exclusions were left out by the build kernels themselves: no filter pass, hoomd/md/NeighborList.cc:423-426)
 
         // setLastUpdatedPos (hoomd/md/NeighborList.cc:1293-1311): the build kernel wrote last_pos
         m_last_L = m_pdata->getGlobalBox().getNearestPlaneDistance();
@@ -768,21 +787,6 @@ void NeighborListGPUBinned::updateExListIdx()
     a.ex_list_indexer = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
     a.N = m_pdata->getN();
     abiCheck(hmd_update_exclusion_list(&a, nullptr), "hmd_update_exclusion_list");
-    }
-
-void NeighborListGPUBinned::filterNlist()
-    {
-    ScopedKernelTimer t("nlist_filter");
-    hmd_nlist_filter_args_t a;
-    std::memset(&a, 0, sizeof(a));
-    a.d_n_neigh = m_n_neigh.get();
-    a.d_nlist = m_nlist.get();
-    a.d_head_list = m_head_list.get();
-    a.d_n_ex = m_n_ex_idx.get();
-    a.d_ex_list = m_ex_list_idx.get();
-    a.exli = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
-    a.N = m_pdata->getN();
-    abiCheck(hmd_nlist_filter(&a, nullptr), "hmd_nlist_filter");
     }
 
 // hoomd/md/NeighborList.cc:1726-1800 (getLocalPairList / getPairList)

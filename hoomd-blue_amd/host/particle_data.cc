@@ -19,6 +19,11 @@ void hipCheck(hipError_t e, const char* what)
         }
     }
 
+unsigned long long hostLayoutFingerprint()
+    {
+    return hostLayoutFingerprintOfTheseHeaders();
+    }
+
 void abiCheck(int code, const char* what)
     {
     if (code == 0)

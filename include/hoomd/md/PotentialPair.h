@@ -277,6 +277,8 @@ template<class T> void export_PotentialPair(pybind11::module& m, const std::stri
     {
     // the base classes are registered by the core module
     pybind11::module::import("hoomd_amd._hoomd_amd");
+    if (hoomd_amd::hostLayoutFingerprintOfTheseHeaders() != hoomd_amd::hostLayoutFingerprint())
+        throw std::runtime_error("pair potential " + name + ": built against other hoomd_amd headers than the installed core module; rebuild it");
     pybind11::class_<PotentialPair<T>, ForceCompute, std::shared_ptr<PotentialPair<T>>>(m, name.c_str())
         .def(pybind11::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<NeighborList>>())
         .def("setParams", &PotentialPair<T>::setParamsPython)

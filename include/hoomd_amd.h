@@ -246,6 +246,12 @@ typedef struct
     unsigned int block_size;
     int filter_body;
     hmd_scalar3 ghost_width;
+    /* Optional (NULL: none): exclusions by particle index, the arrays hmd_update_exclusion_list fills.  Excluded
+       partners are left out while the rows are built, which gives the rows and counts that a build followed by
+       hmd_nlist_filter gives (hoomd/md/NeighborListGPU.cu:158-223), without the second pass over the rows. */
+    const unsigned int* d_n_ex_idx;
+    const unsigned int* d_ex_list_idx; /* entry o of particle i at exli(i, o) */
+    hmd_index2d_t exli;
     } hmd_nlist_binned_args_t;
 int hmd_compute_nlist_binned(const hmd_nlist_binned_args_t* args, void* stream);
 
@@ -855,6 +861,12 @@ typedef struct
                                         (atomicMax) to the largest region population, the capacity later calls on
                                         these rows need */
     size_t tile_nlist_entries;       /* size of d_tile_nlist in 16-bit entries (hmd_nlist_tiles_storage_entries) */
+    /* Optional exclusions by particle index (the arrays hmd_update_exclusion_list fills): excluded partners are
+       left out of the rows while they are built, so rows and d_n_neigh come out as the reference's filter pass
+       (hoomd/md/NeighborListGPU.cu:158-223) leaves them.  d_n_ex_idx NULL: no exclusions. */
+    const unsigned int* d_n_ex_idx;
+    const unsigned int* d_ex_list_idx; /* entry o of particle i at exli(i, o) */
+    hmd_index2d_t exli;
     } hmd_nlist_tiles_args_t;
 int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void* stream);
 

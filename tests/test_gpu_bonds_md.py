@@ -97,17 +97,24 @@ def wca_brute_force(x, L, bonded, r_cut):
     return F, E
 
 
-def test_kremer_grest_melt_forces_exclusions_and_energy_conservation(hoomd):
+@pytest.mark.parametrize("tiles", [False, True])
+def test_kremer_grest_melt_forces_exclusions_and_energy_conservation(hoomd, tiles):
     import lj_liquid
     n, chain = (16, 10, 10), 8
     sim, cell, wca, fene, _ = lj_liquid.make_kg_simulation(hoomd, n, chain_length=chain, sorter_period=20)
     thermo = hoomd.md.compute.ThermodynamicProperties(hoomd.filter.All())
     sim.operations.computes.append(thermo)
+    if tiles:
+        # about three particles per cell: index rows by default; the tile path must give the same (both builds leave
+        # the excluded partners out themselves)
+        cell._attach(sim)
+        cell._cpp_obj.tile_min_occupancy = 0.0
     sim.run(0)
     snap = sim.state.get_snapshot()
     N = snap.particles.N
     assert snap.bonds.N == N // chain * (chain - 1)
     assert cell._cpp_obj.getNumExclusions() == snap.bonds.N
+    assert cell._cpp_obj.tiles_active == tiles
     L = np.array(snap.configuration.box[:3])
     bonded = [set() for _ in range(N)]
     for a, b in snap.bonds.group:

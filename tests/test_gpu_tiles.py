@@ -45,6 +45,57 @@ def test_tile_neighbor_sets_match_oracle(K, A, n, ntypes):
     assert np.array_equal(tl["last_pos"].cpu().numpy()[:N], pos)
 
 
+@pytest.mark.parametrize("n,ntypes,height", [(12, 1, 4), (10, 2, 7), (24, 1, 2)])
+def test_builds_leave_out_exclusions(K, A, n, ntypes, height):
+    """Rows built with exclusions equal the CPU path's build followed by its filter pass
+    (hoomd/md/NeighborListGPU.cu:158-223): chain-like exclusions (i, i+1), (i, i+2) as
+    hoomd/md/test/test_neighborlist.cc:1070-1090, more partners than the kernels keep in registers in one case, and
+    both build kernels (one type: with the fp32 pre-test; two types: the general one)."""
+    xyz, typ, L = liquid(n, ntypes=ntypes, seed=17)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, 2.2]]
+    pos = orc.pack_pos(xyz, typ)
+    n_ex = np.zeros(N, dtype=np.uint32)
+    ex = np.zeros((height, N), dtype=np.uint32)
+    reach = height // 2
+    for i in range(N):
+        if i % 5 == 4:
+            continue  # some particles without exclusions
+        for j in range(i + 1, i + 1 + reach):
+            if j < N and j % 5 != 4:
+                for a_, b_ in ((i, j), (j, i)):
+                    if n_ex[a_] < height:
+                        ex[n_ex[a_], a_] = b_
+                        n_ex[a_] += 1
+    ref = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=True)
+    n_neigh, nlist = ref["n_neigh"].copy(), ref["nlist"].copy()
+    orc.nlist_filter(N, ref["head"], n_ex, ex, n_neigh, nlist)
+    assert (n_neigh < ref["n_neigh"]).sum() > N // 2
+    want = orc.neighbor_sets(n_neigh, nlist, ref["head"])
+    pos_t = torch.from_numpy(pos).cuda()
+    dim = orc.cell_dimensions(obox, 2.9)
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+    ex_t = (torch.from_numpy(n_ex.view(np.int32)).cuda(), torch.from_numpy(ex.view(np.int32)).cuda())
+    tl = K.nlist_tiles(pos_t, N, gbox, r_cut, 0.4, cl, adj, exclusions=ex_t)
+    # the row build with the same exclusions
+    rows = K.nlist_binned(pos_t, N, gbox, r_cut, 0.4, cl, adj, exclusions=ex_t)
+    assert np.array_equal(rows["n_neigh"].cpu().numpy().view(np.uint32)[:N], n_neigh)
+    got_rows = orc.neighbor_sets(rows["n_neigh"].cpu().numpy().view(np.uint32)[:N], rows["nlist"].cpu().numpy().view(np.uint32),
+                                 rows["head"].cpu().numpy().view(np.uint64)[:N])
+    assert all(np.array_equal(g, w) for g, w in zip(got_rows, want))
+    assert np.array_equal(tl["n_neigh"].cpu().numpy().view(np.uint32)[:N], n_neigh)
+    got = expanded_sets(K, tl, N, gbox)
+    for i in range(N):
+        assert np.array_equal(got[i], want[i]), i
+    # forces from the filtered rows (the pairs left out contribute nothing)
+    P = [orc.lj_params(1.0, 1.0)] * (ntypes * ntypes)
+    F_ref, _ = orc.pair_forces(orc.EV_LJ, pos, N, obox, n_neigh, nlist, ref["head"], P, np.square(r_cut), compute_virial=False)
+    F, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, np.square(r_cut), compute_virial=False)
+    assert np.abs(F.cpu().numpy()[:N] - F_ref).max() / np.abs(F_ref).max() < 1e-9
+
+
 def test_tile_triclinic_box(K, A):
     rng = np.random.default_rng(9)
     L, tilt = (14.0, 12.0, 13.0), dict(xy=0.2, xz=-0.1, yz=0.15)

@@ -109,15 +109,15 @@ def test_example_plugin_on_a_liquid_matches_the_oracle(mode, shift):
     sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=1)
     sim.create_state_from_snapshot(snap)
     cell = hoomd.md.nlist.Cell(buffer=0.3)
-    ex = pair_plugin.pair.ExamplePair(cell, default_r_cut=1.6, default_r_on=1.2, mode=mode)
-    ex.params[("A", "A")] = dict(k=30.0, sigma=1.2)
+    ex = pair_plugin.pair.ExamplePair(cell, default_r_cut=2.0, default_r_on=1.5, mode=mode)
+    ex.params[("A", "A")] = dict(k=30.0, sigma=1.5)
     sim.operations.integrator = hoomd.md.Integrator(dt=0.001, methods=[hoomd.md.methods.ConstantVolume(hoomd.filter.All())], forces=[ex])
     sim.run(0)
     assert cell._cpp_obj.tiles_active
     pos = orc.pack_pos(snap.particles.position, snap.particles.typeid)
     obox = orc.Box.from_L(*snap.configuration.box[:3])
-    ref = orc.nlist_binned(pos, N, obox, [[1.6]], 0.3, storage_full=True)
-    F_ref, _ = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(30.0, 1.2)], [[1.6 ** 2]], [[1.2 ** 2]],
+    ref = orc.nlist_binned(pos, N, obox, [[2.0]], 0.3, storage_full=True)
+    F_ref, _ = orc.pair_forces(orc.EV_EXAMPLE, pos, N, obox, ref["n_neigh"], ref["nlist"], ref["head"], [(30.0, 1.5)], [[2.0 ** 2]], [[1.5 ** 2]],
                                shift_mode=shift, compute_virial=False)
     assert np.abs(ex.forces - F_ref[:, :3]).max() / np.abs(F_ref[:, :3]).max() < 1e-6
     assert np.abs(ex.energies - F_ref[:, 3]).max() / np.abs(F_ref[:, 3]).max() < 1e-6
@@ -128,11 +128,11 @@ def test_example_plugin_on_a_liquid_matches_the_oracle(mode, shift):
     d -= L * np.rint(d / L)
     r2 = np.einsum("ijk,ijk->ij", d, d)
     r = np.sqrt(r2)
-    e = np.where(r2 < 1.6 ** 2, 0.5 * 30.0 * (1.2 - r) ** 2, 0.0)
+    e = np.where(r2 < 2.0 ** 2, 0.5 * 30.0 * (1.5 - r) ** 2, 0.0)
     if mode == "shift":
-        e -= np.where(r2 < 1.6 ** 2, 0.5 * 30.0 * (1.2 - 1.6) ** 2, 0.0)
+        e -= np.where(r2 < 2.0 ** 2, 0.5 * 30.0 * (1.5 - 2.0) ** 2, 0.0)
     elif mode == "xplor":
-        rc2, ro2 = 1.6 ** 2, 1.2 ** 2
+        rc2, ro2 = 2.0 ** 2, 1.5 ** 2
         sw = (rc2 - r2) ** 2 * (rc2 + 2 * r2 - 3 * ro2) / (rc2 - ro2) ** 3
         e *= np.where(r2 >= ro2, sw, 1.0)
     assert abs(ex.compute_energy(even, odd) - e.sum()) / abs(e.sum()) < 1e-10
