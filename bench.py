@@ -16,9 +16,10 @@ exchange over RCCL.  Rank 0 prints one JSON line.
 `roofline` prices the pair-force kernel: algorithmic bytes per launch = 4 * (listed neighbors) +
 76 * N, divided by the kernel's average duration measured with HIP events on the launch stream
 inside the timed region; `fp64_tflops` is 37 flop per listed pair (minimum image excluded: the tile path has
-none) over the same duration, next to the 78.6 TFLOP/s fp64 vector peak, so that an ALU-bound kernel shows.  `cpu_baseline` times the CPU oracle (a C restatement of the reference's
-CPU path: half neighbor list + Newton's third law) on a bounded sample, one replica per host core of
-this process's CPU share, all at the same time.
+none) over the same duration, next to the 78.6 TFLOP/s fp64 vector peak, so that an ALU-bound kernel shows.
+`cpu_baseline` times the CPU oracle (a C restatement of the reference's CPU path: half neighbor list + Newton's
+third law) as ONE domain-decomposed run over the host cores of this process's CPU share, started from the state the
+GPU run ended in, for a bounded number of steps.
 """
 import argparse
 import json
@@ -41,66 +42,58 @@ def grid_for(n):
     return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline_replica():
-    """Reference CPU path (oracle) on one core: 64 x 64 x 32 lattice (N = 131,072, same density,
-    temperature, cutoff and buffer), 40 NVE steps from the lattice start including every neighbor
-    list rebuild that the distance check triggers.  Returns (N, steps, seconds, rebuilds)."""
-    import numpy as np
-    import lj_liquid
-    from oracle import oracle as orc
-
-    n = (64, 64, 32)
-    pos, L = lj_liquid.lattice(n)
-    N = len(pos)
-    vel = np.concatenate([lj_liquid.velocities(N), np.ones((N, 1))], axis=1)
-    sim = orc.Sim(orc.pack_pos(pos, np.zeros(N, dtype=int)), vel, L, r_cut=2.5, r_buff=0.4, dt=0.005)
-    sim.run(0)
-    steps = 40
-    t0 = time.perf_counter()
-    sim.run(steps)
-    dt = time.perf_counter() - t0
-    return N, steps, dt, sim.stats()["num_builds"], n
-
-
-def cpu_baseline():
-    """The reference's CPU mode uses one MPI rank per core, each with its own sub-box.  Here: one replica of
-    the one-core sample per core of this process's CPU share (at most 16), all running at the same time, so
-    the figure includes what the cores cost each other in memory bandwidth; they exchange no halos, which
-    makes it an upper bound for a decomposed run on these cores."""
+def cpu_baseline(snapshot, steps=150):
+    """The reference's CPU mode is one MPI rank per core, each with its own sub-box and ghost layer.  Here: the
+    oracle's restatement of that CPU path (binned half list with ghosts, third-law pair loop, velocity Verlet,
+    distance check) on one sub-box per core of this process's CPU share (at most 15), halos / migration / rebuild vote
+    over gloo (scripts/cpu_decomposed.py), started from the state the GPU run ended in -- same N, same liquid --
+    for a bounded number of steps."""
     import subprocess
+    import tempfile
+    import numpy as np
     try:
         share = len(os.sched_getaffinity(0))
     except AttributeError:
         share = os.cpu_count() or 1
-    cores = max(1, min(16, share))
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-replica"], stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1")) for _ in range(cores)]
-    res = []
-    for p in procs:
-        out, _ = p.communicate(timeout=600)
-        if p.returncode == 0:
-            res.append(json.loads(out.decode().strip().splitlines()[-1]))
-    wall = time.perf_counter() - t0
-    if not res:
-        raise RuntimeError("no CPU baseline replica finished")
-    N, steps, n, builds = res[0]["N"], res[0]["steps"], res[0]["n"], res[0]["builds"]
-    slowest = max(r["seconds"] for r in res)
+    # (15, not 16: this process keeps the GPU, and a GPU box admits 16 processes of one job in all)
+    cores = max(1, min(15, share))
+    L = np.asarray(snapshot.configuration.box[:3], dtype=np.float64)
+    pos = np.asarray(snapshot.particles.position, dtype=np.float64)
+    pos = pos - np.floor((pos + L / 2) / L) * L
+    with tempfile.TemporaryDirectory() as tmp:
+        state, out = os.path.join(tmp, "state.npz"), os.path.join(tmp, "out.json")
+        np.savez(state, position=pos, velocity=np.asarray(snapshot.particles.velocity, dtype=np.float64), L=L)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        script = os.path.join(ROOT, "scripts", "cpu_decomposed.py")
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, script, str(r), str(cores), str(port), state, str(steps), out], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.PIPE, env=env) for r in range(cores)]
+        errs = [p.communicate(timeout=900)[1] for p in procs]
+        wall = time.perf_counter() - t0
+        bad = [r for r, p in enumerate(procs) if p.returncode != 0]
+        if bad:
+            raise RuntimeError(f"CPU baseline rank {bad[0]} failed: {errs[bad[0]].decode(errors='replace')[-2000:]}")
+        with open(out) as f:
+            res = json.load(f)
+    N = res["N"]
     return {
-        "value": len(res) * N * steps / slowest, "unit": "particle-steps/s", "cores": len(res), "kind": "port",
-        "sample": f"{len(res)} replicas at once, one per core, of: LJ liquid {n[0]}x{n[1]}x{n[2]} lattice (N={N}), {steps} NVE steps from the "
-                  f"lattice start, {builds} neighbor-list rebuilds; half list + third law; slowest replica {slowest:.1f} s "
-                  f"({wall:.1f} s with start-up); no halo exchange between the replicas",
-        "fastest_replica_value": N * steps / min(r["seconds"] for r in res),
-        "timesteps_per_s_at_sample_N": steps / slowest,
+        "value": N * res["steps"] / res["seconds"], "unit": "particle-steps/s", "cores": cores, "kind": "port",
+        "launcher": f"{cores} processes (one per core, OMP_NUM_THREADS=1), torch.distributed gloo over 127.0.0.1, scripts/cpu_decomposed.py",
+        "sample": f"ONE decomposed run of the same system from the state the GPU run ended in: N={N}, domain grid {res['grid']}, "
+                  f"{res['steps']} NVE steps in {res['seconds']:.1f} s ({wall:.1f} s with start-up), {res['rebuilds']} neighbor-list rebuilds with migration + ghost "
+                  f"exchange, ghost positions every other step, {res['mean_ghosts_per_rank']:.0f} ghosts per rank; half list + third law per rank",
+        "timesteps_per_s": res["steps"] / res["seconds"],
+        "total_energy_per_particle_at_end": (res["kinetic_energy"] + res["potential_energy"]) / N,
     }
 
 
 def main():
-    if "--cpu-baseline-replica" in sys.argv:
-        N, steps, dt, builds, n = cpu_baseline_replica()
-        print(json.dumps({"N": N, "steps": steps, "seconds": dt, "builds": int(builds), "n": list(n)}), flush=True)
-        return
     # Libraries print banners on the C-level standard output (RCCL does at start-up): everything written to
     # file descriptor 1 goes to standard error until the result line, which is then the only line on stdout.
     sys.stdout.flush()
@@ -121,6 +114,7 @@ def main():
     ap.add_argument("--time-all", action="store_true", help="time every kernel family with HIP events (perturbs the run) and print the table to stderr")
     ap.add_argument("--cprofile", action="store_true", help="profile the host side of the timed region (rank 0, to stderr)")
     ap.add_argument("--force-dd", action="store_true", help="run the domain-decomposition code path even on one rank (rehearsal of the RCCL calls)")
+    ap.add_argument("--cpu-steps", type=int, default=150, help="steps of the decomposed CPU baseline run (about 0.1 s each on 16 cores at N = 2^20)")
     ap.add_argument("--no-tiles", action="store_true", help="force the neighbor list to index rows (the tile path is chosen by cell occupancy otherwise)")
     ap.add_argument("--no-overlap", action="store_true", help="domain decomposition: do not compute interior blocks during the halo exchange")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
@@ -303,7 +297,10 @@ def main():
                 "steps_with_forces_overlapping_the_exchange": int(cell._cpp_obj.num_overlapped),
                 "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.exchange.n_vote_exchanges)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            if args.workload == "lj":
+                out["cpu_baseline"] = cpu_baseline(sim.state.get_snapshot(), args.cpu_steps)
+            else:
+                out["cpu_baseline"] = None  # the CPU port covers the headline workload
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -82,3 +82,39 @@ def test_grid_choice_minimises_surface():
     assert comm.find_grid(1, [1.0, 1.0, 1.0]) == (1, 1, 1)
     for n in (2, 3, 4, 6, 8, 12):
         assert int(np.prod(comm.find_grid(n, [3.0, 2.0, 1.0]))) == n
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_decomposed_cpu_baseline_matches_the_single_domain_cpu_path(tmp_path, world):
+    """scripts/cpu_decomposed.py (the CPU baseline of the benchmark: the oracle's per-domain step driven by the gloo
+    exchange) against the oracle's single-domain run from the same state: same energies after the same number of
+    steps, with rebuilds and migration on the way."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "scripts"))
+    import lj_liquid
+    from oracle import oracle as orc
+    n = (14, 14, 14)
+    pos, L = lj_liquid.lattice(n)
+    rng = np.random.default_rng(3)
+    pos = pos + rng.normal(0, 0.08, pos.shape)
+    pos -= np.floor((pos + L / 2) / L) * L
+    N = len(pos)
+    vel = lj_liquid.velocities(N, 1.5, 7)
+    state = str(tmp_path / "state.npz")
+    np.savez(state, position=pos, velocity=vel, L=L)
+    steps = 40
+    outs = []
+    out = str(tmp_path / "out.json")
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(HERE), "scripts", "cpu_decomposed.py"), str(r), str(world), str(port), state,
+                               str(steps), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        o, _ = p.communicate(timeout=240)
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    res = json.load(open(out))
+    assert res["N"] == N and res["ranks"] == world and res["rebuilds"] >= 3 and res["mean_ghosts_per_rank"] > 0
+    ref = orc.Sim(orc.pack_pos(pos, np.zeros(N, dtype=int)), np.concatenate([vel, np.ones((N, 1))], 1), L)
+    ref.run(steps + 2)  # the worker runs two untimed steps first
+    ke, pe = ref.energies()
+    assert res["kinetic_energy"] == pytest.approx(ke, rel=1e-9) and res["potential_energy"] == pytest.approx(pe, rel=1e-9)
