@@ -250,7 +250,7 @@ def main():
     # process, so the figure measured for this configuration is carried in profiles/
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
             tr = json.load(f)
         if tr.get("N") == n_local and world == 1:
             traffic = tr["kernels"]["pair_force_tiles_kernel"]["hbm_bytes_per_launch"]

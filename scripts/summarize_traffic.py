@@ -29,7 +29,7 @@ write = per_kernel(out + "/write", "WRITE_SIZE")
 
 
 def short(n):
-    for k in ("pair_force_tiles_kernel", "pair_force_kernel", "nlist_binned_kernel", "fused_step_kernel", "cell_list_kernel", "step_one_kernel",
+    for k in ("pair_force_tiles_kernel", "pair_force_kernel", "nlist_pref_kernel", "nlist_binned_kernel", "tile_block_groups_kernel", "fused_step_kernel", "cell_list_kernel", "step_one_kernel",
               "step_two_kernel", "nlist_check_kernel"):
         if k in n:
             return k
