@@ -295,7 +295,7 @@ def main():
             out["config"]["decomposition"] = {
                 "backend": dist.get_backend(), "exchange_stream_high_priority": bool(cell._cpp_obj.comm_stream_high_priority),
                 "steps_with_forces_overlapping_the_exchange": int(cell._cpp_obj.num_overlapped),
-                "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.exchange.n_vote_exchanges)}
+                "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.n_vote_exchanges)}
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "lj":
                 out["cpu_baseline"] = cpu_baseline(sim.state.get_snapshot(), args.cpu_steps)

@@ -284,6 +284,8 @@ _SIGNATURES = {
     "hmd_cell_order": (C.c_int, [C.POINTER(CellOrderArgs), vp]),
     "hmd_gather_rows": (C.c_int, [vp, vp, vp, u32, u32, vp]),
     "hmd_build_rtag": (C.c_int, [vp, vp, u32, vp]),
+    "hmd_sort_keys_workspace_bytes": (C.c_size_t, [u32]),
+    "hmd_sort_keys": (C.c_int, [vp, vp, u32, u32, vp, C.c_size_t, vp]),
     "hmd_make_ghost_exchange_plan": (C.c_int, [C.POINTER(GhostPlanArgs), vp]),
     "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
     "hmd_nve_step_two_one_check": (C.c_int, [C.POINTER(FusedStepArgs), vp]),

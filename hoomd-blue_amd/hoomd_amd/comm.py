@@ -5,16 +5,13 @@ Role of hoomd/DomainDecomposition.cc (grid choice :327-408, sub-box bounds), hoo
 (communicate :1510-1569, migrateParticles, exchangeGhosts, beginUpdateGhosts) and
 hoomd/CommunicatorGPU.cu (ghost plan :306-358, pack with periodic shift :789-875).
 
-Design for point-to-point xGMI rather than staged MPI sweeps: every (particle, direction) ghost image
-is one entry of a single send list sorted by destination rank, so a time step needs ONE pack kernel
-and ONE ``all_to_all_single`` that lands directly in the ghost tail ``pos[N : N + n_ghost)`` of the
-receiver; edges and corners are separate entries, not forwarded copies.  Migration (rebuild steps
-only) routes a leaving particle straight to its owner rank, however far away.
-
-Ghost forces are never sent back: the neighbor list is full, so each rank computes both i<-j and
-j<-i for the particles it owns.
+The exchange itself (migration, ghost layer, per-step ghost update, rebuild vote) is the C++ class
+``_cpp.CommunicatorGPU`` (host/communicator.cc); this module sets the decomposition up (grid, sub-boxes,
+scatter / gather of snapshots), provides the message-passing layer the C++ class calls (``TorchTransport``:
+``all_to_all_single`` / ``all_reduce`` on the device buffers) and keeps the tensor-operation form of the same
+protocol for CPU tensors (``ParticleExchange``: host-side tests and the CPU baseline).
 """
-import ctypes
+import contextlib
 import itertools
 import os
 
@@ -96,11 +93,6 @@ class HostArrays:
 class _DevMem:
     def __init__(self, ptr, shape, typestr):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-
-
-def _abi():
-    from . import _abi as m
-    return m
 
 
 class PDataArrays:
@@ -245,16 +237,16 @@ class DomainDecomposition:
     def _attach(self, sim):
         self._sim = sim
         self.communicator = Communicator(self, sim._state._sysdef)
-        sim._state._sysdef.setCommunicator(self.communicator)
+        sim._state._sysdef.setCommunicator(self.communicator.cpp)
 
     def _nlist_attached(self, nlist):
-        self.communicator.nlists.append(nlist)
-        if nlist._cpp_obj is not None and self.ranks_share_a_gpu():
+        self.communicator.add_nlist(nlist)
+        if self.ranks_share_a_gpu():
             nlist._cpp_obj.comm_stream_high_priority = False
 
     def _allreduce_sum_list(self, values):
-        ex = self.communicator.exchange if self.communicator is not None else None
-        dev = ex.device if ex is not None and not ex._stage else "cpu"
+        tr = self.communicator.transport if self.communicator is not None else None
+        dev = tr.device if tr is not None and not tr.stage else "cpu"
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.tolist()
@@ -284,23 +276,21 @@ class DomainDecomposition:
                 local[k] = np.ascontiguousarray(v[mine])
         pdata.initializeFromSnapshot(local)
         if self.communicator is not None:
-            self.communicator.exchange.arrays.refresh()
-            self.communicator.forceMigrate()
+            self.communicator.cpp.forceMigrate()
 
 
 class ParticleExchange:
-    """Device-agnostic migration and halo exchange on a set of per-particle arrays.
+    """Migration and halo exchange written with tensor operations on a set of per-particle arrays (``HostArrays``).
 
-    ``arrays`` provides N, n_ghosts, the tensors pos/vel/accel/image/tag/body/charge/diameter/rtag and
-    resize_owned / set_n_ghosts / notify_sort.  All collectives are ``all_to_all_single`` over
-    ``decomposition.group``."""
+    The same protocol as the C++ communicator of the GPU path (``_cpp.CommunicatorGPU``: one send list sorted by
+    destination rank, one ``all_to_all_single`` per exchange), for CPU tensors over gloo: the host-side tests of the
+    decomposition logic and the decomposed CPU baseline of the benchmark run on it.  ``arrays`` provides N, n_ghosts,
+    the tensors pos/vel/accel/image/tag/body/charge/diameter/rtag and resize_owned / set_n_ghosts / notify_sort."""
 
-    def __init__(self, decomposition, arrays, pack_fn=None):
+    def __init__(self, decomposition, arrays):
         self.dd = decomposition
         self.arrays = arrays
         self.device = arrays.pos.device
-        self.pack_fn = pack_fn
-        self._stage = dist.get_backend(decomposition.group) == "gloo" and self.device.type != "cpu"
         dd = decomposition
         # one entry per direction towards a neighbor domain, sorted by destination rank
         dirs = []
@@ -338,55 +328,10 @@ class ParticleExchange:
         self.n_migrated_out = 0
         self.n_migrated_in = 0
         self._vote = None
-        self._mig_dest = None
-        self._mig_fixed = None
-        self._mig_slot_rows = int(os.environ.get("HOOMD_AMD_MIGRATE_SLOT_ROWS", "1024"))
-        # fixed-size migration messages: when every other rank is a neighbor of this one
-        peers = [r for r in range(dd.world) if r != dd.rank]
-        self._fixed_migrate = (self.device.type == "cuda" and 2 <= dd.world <= 64 and sorted(set(self.dir_dest)) == peers
-                               and os.environ.get("HOOMD_AMD_FIXED_MIGRATE", "1") != "0")
-        self._mig_counters = None
-        self._mig_keys = None
-        self._mig_empty = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
-        self._mig_empty_in = torch.zeros((0, _ELEM), dtype=torch.int64, device=self.device)
-        self._r_ghost = None
-        self._r_ghost_value = None
-        self.vote_plan = None
-        self._vote_out = None
-        self._vote_in = None
-        self.n_vote_exchanges = 0
-        self._keys = None
-        self._send_counters = None
-        self._send_buf = None
-        self._pdata_cache = None
-        self._init_buf = None
-        self._plan_buf = None
-        self._stream = None  # HIP stream handle for the per-step exchange kernels (None = the default stream)
-        self._pinned = {}
 
     # ---- collectives ----
-    def _pinned_like(self, name, t):
-        """A pinned host tensor of t's shape and dtype, carved from a buffer that is kept between calls."""
-        nbytes = t.numel() * t.element_size()
-        buf = self._pinned.get(name)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
-            self._pinned[name] = buf
-        return buf[:nbytes].view(t.dtype).view(t.shape)
-
     def _a2a(self, out, inp, out_splits, in_splits):
-        if self._stage:
-            # gloo cannot move device memory (tests only): stage through pinned host buffers with asynchronous copies on
-            # the stream the exchange kernels run on, and wait for exactly that stream
-            stream = torch.cuda.current_stream(self.device)
-            hin, hout = self._pinned_like("in", inp), self._pinned_like("out", out)
-            hin.copy_(inp, non_blocking=True)
-            stream.synchronize()
-            dist.all_to_all_single(hout, hin, out_splits, in_splits, group=self.dd.group)
-            out.copy_(hout, non_blocking=True)
-            stream.synchronize()  # the buffers are reused by the next call
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.dd.group)
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.dd.group)
 
     def _exchange_counts(self, send_counts):
         s = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
@@ -396,120 +341,6 @@ class ParticleExchange:
 
     # ---- migration (hoomd/Communicator.cc migrateParticles) ----
     def migrate(self):
-        if self.device.type == "cuda":
-            return self._migrate_kernels()
-        return self._migrate_tensor_ops()
-
-    def _pdata_struct(self):
-        A, m = self.arrays, _abi()
-        gen = getattr(A, "generation", None)  # changes whenever the device arrays are bound anew
-        if gen is not None and self._pdata_cache is not None and self._pdata_cache[0] == gen:
-            return self._pdata_cache[1]
-        p = m.PDataArraysStruct()
-        p.d_pos, p.d_vel, p.d_accel, p.d_image = A.pos.data_ptr(), A.vel.data_ptr(), A.accel.data_ptr(), A.image.data_ptr()
-        p.d_tag, p.d_body, p.d_charge, p.d_diameter = A.tag.data_ptr(), A.body.data_ptr(), A.charge.data_ptr(), A.diameter.data_ptr()
-        self._pdata_cache = (gen, p)
-        return p
-
-    def _migrate_kernels(self):
-        """Migration with one kernel per stage: owners + leaver keys + counts per owner, one readback, a sort
-        of the (few) keys, pack, the two collectives, gap filling, unpack."""
-        A, dd, m = self.arrays, self.dd, _abi()
-        N = A.N
-        A.set_n_ghosts(0)  # ghosts are re-exchanged afterwards
-        world = dd.world
-        if self._mig_dest is None or self._mig_dest.numel() < max(N, 1):
-            self._mig_dest = torch.empty(int(max(N, 1) * 1.125) + 64, dtype=torch.int32, device=self.device)
-        if self._mig_counters is None:
-            self._mig_counters = torch.zeros(1 + world, dtype=torch.int32, device=self.device)
-            self._mig_keys = torch.empty(4096, dtype=torch.int64, device=self.device)
-        a = m.MigrateDestArgs()
-        a.d_pos, a.N, a.rank = A.pos.data_ptr(), N, dd.rank
-        a.global_lo[:], a.global_L[:], a.grid[:] = list(dd.glo), list(dd.gL), list(dd.grid)
-        a.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
-        a.d_dest = self._mig_dest.data_ptr()
-        a.d_n_leave, a.d_rank_count, a.n_ranks = self._mig_counters.data_ptr(), self._mig_counters.data_ptr() + 4, world
-        while True:
-            self._mig_counters.zero_()
-            a.d_keys, a.capacity = self._mig_keys.data_ptr(), int(self._mig_keys.numel())
-            m.check(m.lib.hmd_migrate_dest(ctypes.byref(a), None), "hmd_migrate_dest")
-            counters = self._mig_counters.tolist()
-            if counters[0] <= self._mig_keys.numel():
-                break
-            self._mig_keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
-        n_leave, send_counts = counters[0], counters[1:]
-        keys = None
-        if n_leave:
-            keys, _ = torch.sort(self._mig_keys[:n_leave])
-        pk = m.MigratePackArgs()
-        pk.arrays, pk.d_keys, pk.n = self._pdata_struct(), (keys.data_ptr() if n_leave else None), n_leave
-        pk.global_lo[:], pk.global_L[:] = list(dd.glo), list(dd.gL)
-        pk.decomposed[:] = [int(bool(v)) for v in dd.decomposed]
-        slot_rows = 0
-        if self._fixed_migrate:
-            # Every rank exchanges with every other rank: messages of a fixed number of rows, each headed by its
-            # particle count and the sender's largest count.  All ranks see all headers, so all of them know
-            # every message size, and whether any message was too small, without an exchange of counts.
-            off = 0
-            for r in range(world):
-                pk.send_off[r] = off
-                off += send_counts[r]
-            pk.send_off[world] = off
-            pk.n_ranks = world
-            while True:
-                slot_rows = self._mig_slot_rows
-                rows = world * (slot_rows + 1)
-                if self._mig_fixed is None or self._mig_fixed[0].shape[0] < rows:
-                    self._mig_fixed = (torch.zeros((rows, _ELEM), dtype=torch.int64, device=self.device),
-                                       torch.zeros((rows, _ELEM), dtype=torch.int64, device=self.device))
-                payload, incoming = self._mig_fixed[0][:rows], self._mig_fixed[1][:rows]
-                pk.slot_rows, pk.d_out = slot_rows, payload.data_ptr()
-                m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
-                self._a2a(incoming, payload, None, None)
-                headers = incoming.view(world, slot_rows + 1, _ELEM)[:, 0, :2].tolist()
-                most = max(h[1] for h in headers)
-                if most <= slot_rows:
-                    break
-                self._mig_slot_rows = 2 * int(most)  # the same decision on every rank: send again with room for all
-            recv_counts = [int(h[0]) for h in headers]
-            n_recv = sum(recv_counts)
-        else:
-            payload = self._mig_empty
-            if n_leave:
-                payload = torch.empty((n_leave, _ELEM), dtype=torch.int64, device=self.device)
-                pk.d_out = payload.data_ptr()
-                m.check(m.lib.hmd_migrate_pack(ctypes.byref(pk), None), "hmd_migrate_pack")
-            recv_counts = self._exchange_counts(send_counts)
-            n_recv = sum(recv_counts)
-            # every rank takes part in the collective, also with nothing to send or receive
-            incoming = torch.empty((n_recv, _ELEM), dtype=torch.int64, device=self.device) if n_recv else self._mig_empty_in
-            self._a2a(incoming, payload, recv_counts, send_counts)
-        self.n_migrated_out += n_leave
-        self.n_migrated_in += n_recv
-        if n_leave == 0 and n_recv == 0:
-            return False
-        n_keep = N - n_leave
-        if n_leave:
-            scratch = torch.empty(2 * n_leave, dtype=torch.int32, device=self.device)
-            f = m.MigrateFillArgs()
-            f.arrays, f.d_dest, f.rank, f.N = self._pdata_struct(), self._mig_dest.data_ptr(), dd.rank, N
-            f.d_keys, f.n_leave, f.d_scratch = keys.data_ptr(), n_leave, scratch.data_ptr()
-            m.check(m.lib.hmd_migrate_fill(ctypes.byref(f), None), "hmd_migrate_fill")
-        A.resize_owned(n_keep + n_recv)  # (keeps the contents when it has to reallocate)
-        if n_recv:
-            u = m.MigrateUnpackArgs()
-            u.arrays, u.d_in, u.first, u.n = self._pdata_struct(), incoming.data_ptr(), n_keep, n_recv
-            if slot_rows:
-                u.slot_rows, u.n_ranks = slot_rows, world
-                off = 0
-                for r in range(world):
-                    u.recv_off[r] = off
-                    off += recv_counts[r]
-                u.recv_off[world] = off
-            m.check(m.lib.hmd_migrate_unpack(ctypes.byref(u), None), "hmd_migrate_unpack")
-        return True
-
-    def _migrate_tensor_ops(self):
         A, dd = self.arrays, self.dd
         N = A.N
         A.set_n_ghosts(0)  # ghosts are re-exchanged afterwards
@@ -574,62 +405,25 @@ class ParticleExchange:
             if dd.decomposed[a] and width[a] <= 2.0 * r_ghost:
                 raise RuntimeError("Simulation box too small for domain decomposition: a sub-box must be wider than twice the ghost layer")
         ndir = len(self.dir_dest)
-        if self.device.type == "cuda":
-            # plan, per-direction selection and counts in one kernel; one readback; one sort puts the keys
-            # (direction, particle index) in the order of the send list
-            m = _abi()
-            ntypes = max(int(getattr(A, "ntypes", 1)), 1)
-            if self._r_ghost is None or self._r_ghost.numel() != ntypes or float(self._r_ghost_value) != float(r_ghost):
-                self._r_ghost = torch.full((ntypes,), float(r_ghost), dtype=torch.float64, device=self.device)
-                self._r_ghost_value = float(r_ghost)
-            if self._keys is None:
-                self._keys = torch.empty(max(N // 2, 1024), dtype=torch.int64, device=self.device)
-                self._send_counters = torch.zeros(1 + 26, dtype=torch.int32, device=self.device)
-            a = m.GhostSendListArgs()
-            a.ghost_plan.d_plan, a.ghost_plan.d_pos, a.ghost_plan.N = None, A.pos.data_ptr(), N
-            a.ghost_plan.box = m.Box.from_lo_hi(list(dd.lo), list(dd.hi))
-            a.ghost_plan.d_r_ghost, a.ghost_plan.ntypes = self._r_ghost.data_ptr(), ntypes
-            a.ghost_plan.mask = sum(3 << (2 * ax) for ax in range(3) if dd.decomposed[ax])
-            a.d_dir_mask, a.n_dir = self.dir_mask.data_ptr(), ndir
-            while True:
-                self._send_counters.zero_()
-                a.d_keys, a.capacity = self._keys.data_ptr(), int(self._keys.numel())
-                a.d_total, a.d_dir_count = self._send_counters.data_ptr(), self._send_counters.data_ptr() + 4
-                m.check(m.lib.hmd_ghost_send_list(ctypes.byref(a), None), "hmd_ghost_send_list")
-                counters = self._send_counters.tolist()
-                if counters[0] <= self._keys.numel():
-                    break
-                self._keys = torch.empty(int(counters[0] * 1.25) + 1024, dtype=torch.int64, device=self.device)
-            total, per_dir = counters[0], counters[1:1 + ndir]
-            keys, _ = torch.sort(self._keys[:total])
-            if self._send_buf is None or self._send_buf[0].numel() < total:
-                cap = int(total * 1.25) + 1024
-                self._send_buf = (torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, dtype=torch.uint8, device=self.device))
-            self.send_idx32, self.send_dir = self._send_buf[0][:total], self._send_buf[1][:total]
-            m.check(m.lib.hmd_ghost_split_keys(keys.data_ptr(), total, self.send_idx32.data_ptr(), self.send_dir.data_ptr(), None), "hmd_ghost_split_keys")
-            self.send_idx = self.send_shift = None  # (only the tensor-operation path uses them)
+        x = A.pos[:N, :3]
+        f = (x - self.lo) / (self.hi - self.lo)
+        g = r_ghost / (self.hi - self.lo)
+        bits = torch.tensor([[1, 4, 16], [2, 8, 32]], dtype=torch.int32, device=self.device)
+        decm = self.dec.to(torch.int32)
+        plan = (((f >= (1.0 - g)).to(torch.int32) * bits[0] + (f < g).to(torch.int32) * bits[1]) * decm).sum(dim=1, dtype=torch.int32)
+        b = torch.nonzero(plan).flatten()
+        if ndir and b.numel():
+            m = (plan[b][None, :] & self.dir_mask[:, None]) == self.dir_mask[:, None]   # [ndir, nb]
+            nz = torch.nonzero(m)
+            per_dir = m.sum(dim=1).tolist()
+            self.send_idx = b[nz[:, 1]].contiguous()
+            self.send_dir = nz[:, 0].to(torch.uint8).contiguous()
+            self.send_shift = self.shift_table[nz[:, 0]].contiguous()
         else:
-            x = A.pos[:N, :3]
-            f = (x - self.lo) / (self.hi - self.lo)
-            g = r_ghost / (self.hi - self.lo)
-            bits = torch.tensor([[1, 4, 16], [2, 8, 32]], dtype=torch.int32, device=self.device)
-            decm = self.dec.to(torch.int32)
-            plan = (((f >= (1.0 - g)).to(torch.int32) * bits[0] + (f < g).to(torch.int32) * bits[1]) * decm).sum(dim=1, dtype=torch.int32)
-            b = torch.nonzero(plan).flatten()
-            if ndir and b.numel():
-                m = (plan[b][None, :] & self.dir_mask[:, None]) == self.dir_mask[:, None]   # [ndir, nb]
-                nz = torch.nonzero(m)
-                per_dir = m.sum(dim=1).tolist()
-                self.send_idx = b[nz[:, 1]].contiguous()
-                self.send_dir = nz[:, 0].to(torch.uint8).contiguous()
-                self.send_shift = self.shift_table[nz[:, 0]].contiguous()
-            else:
-                per_dir = [0] * ndir
-                self.send_idx = torch.zeros(0, dtype=torch.int64, device=self.device)
-                self.send_dir = torch.zeros(0, dtype=torch.uint8, device=self.device)
-                self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=self.device)
-        if self.device.type != "cuda":
-            self.send_idx32 = self.send_idx.to(torch.int32)
+            per_dir = [0] * ndir
+            self.send_idx = torch.zeros(0, dtype=torch.int64, device=self.device)
+            self.send_dir = torch.zeros(0, dtype=torch.uint8, device=self.device)
+            self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=self.device)
         send_counts = [0] * dd.world
         for k, n in enumerate(per_dir):
             send_counts[self.dir_dest[k]] += int(n)
@@ -638,99 +432,18 @@ class ParticleExchange:
         n_ghost = sum(self.recv_splits)
         A.set_n_ghosts(n_ghost)
         s = slice(N, N + n_ghost)
-        if self.device.type == "cuda":
-            # one message per peer carries position, type and tag; the unpack kernel also sets the fields
-            # that are not communicated
-            m = _abi()
-            n_send = int(self.send_idx32.numel())
-            if self._init_buf is None or self._init_buf[0].shape[0] < n_send or self._init_buf[1].shape[0] < n_ghost:
-                self._init_buf = (torch.empty((int(n_send * 1.25) + 64, 4), dtype=torch.float64, device=self.device),
-                                  torch.empty((int(n_ghost * 1.25) + 64, 4), dtype=torch.float64, device=self.device))
-            out, inc = self._init_buf[0][:n_send], self._init_buf[1][:n_ghost]
-            pa = m.PackPosArgs()
-            pa.d_out, pa.d_pos, pa.d_send_idx, pa.d_send_shift_id = out.data_ptr(), A.pos.data_ptr(), self.send_idx32.data_ptr(), self.send_dir.data_ptr()
-            pa.d_shift_table, pa.n_send = self.shift_table.data_ptr(), n_send
-            m.check(m.lib.hmd_pack_ghost_init(ctypes.byref(pa), A.tag.data_ptr(), None), "hmd_pack_ghost_init")
-            self._a2a(inc, out, self.recv_splits, self.send_splits)
-            u = m.UnpackGhostInitArgs()
-            u.d_in, u.n, u.first, u.arrays = inc.data_ptr(), n_ghost, N, self._pdata_struct()
-            m.check(m.lib.hmd_unpack_ghost_init(ctypes.byref(u), None), "hmd_unpack_ghost_init")
-        else:
-            self._a2a(A.tag[s], A.tag[self.send_idx].contiguous(), self.recv_splits, self.send_splits)
-            A.body[s] = -1
-            A.charge[s] = 0.0
-            A.diameter[s] = 1.0
-            A.image[s] = 0
-            self.update_ghosts()
-        self._build_vote_plan(n_ghost)
+        self._a2a(A.tag[s], A.tag[self.send_idx].contiguous(), self.recv_splits, self.send_splits)
+        A.body[s] = -1
+        A.charge[s] = 0.0
+        A.diameter[s] = 1.0
+        A.image[s] = 0
+        self.update_ghosts()
         A.rtag.fill_(NOT_LOCAL)
         n_all = N + n_ghost
-        if self.device.type == "cuda":
-            _abi().check(_abi().lib.hmd_build_rtag(A.rtag.data_ptr(), A.tag.data_ptr(), n_all, None), "hmd_build_rtag")
-        else:
-            A.rtag[A.tag[:n_all].to(torch.int64)] = torch.arange(n_all, dtype=torch.int32, device=self.device)
-
-    def _build_vote_plan(self, n_ghost):
-        """Row maps for the halo exchange that also carries the rebuild vote: every message gets one extra row.
-        Only when this rank exchanges ghosts with every other rank (then the maximum over the received rows and
-        the own flag is the maximum over all ranks) and the arrays are on the GPU."""
-        dd = self.dd
-        self.vote_plan = None
-        peers = [r for r in range(dd.world) if r != dd.rank]
-        if self.device.type != "cuda" or not peers or sorted(set(self.dir_dest)) != peers:
-            return
-        send, recv = self.send_splits, self.recv_splits
-        m = _abi()
-        if dd.world > m.VOTE_PLAN_MAX_RANKS:
-            return
-        aug_send = [send[r] + (r != dd.rank) for r in range(dd.world)]
-        aug_recv = [recv[r] + (r != dd.rank) for r in range(dd.world)]
-        n_send, n_in, n_out = sum(send), sum(aug_recv), sum(aug_send)
-        assert sum(recv) == n_ghost
-        dev = self.device
-        if self._plan_buf is None or self._plan_buf[0].numel() < n_send or self._plan_buf[2].numel() < n_in:
-            self._plan_buf = (torch.empty(int(n_send * 1.25) + 64, dtype=torch.int32, device=dev),
-                              torch.empty(dd.world, dtype=torch.int32, device=dev),
-                              torch.empty(int(n_in * 1.25) + 64, dtype=torch.int32, device=dev))
-        a = m.VotePlanArgs()
-        a.n_ranks, a.rank = dd.world, dd.rank
-        so = ro = 0
-        for r in range(dd.world):
-            a.send_off[r], a.recv_off[r] = so, ro
-            so += send[r]
-            ro += recv[r]
-        a.send_off[dd.world], a.recv_off[dd.world] = so, ro
-        out_row, flag_rows, in_map = self._plan_buf[0][:n_send], self._plan_buf[1][:dd.world - 1], self._plan_buf[2][:n_in]
-        a.d_out_row, a.d_flag_rows, a.d_in_map = out_row.data_ptr(), flag_rows.data_ptr(), in_map.data_ptr()
-        m.check(m.lib.hmd_vote_plan(ctypes.byref(a), None), "hmd_vote_plan")
-        self.vote_plan = dict(aug_send=aug_send, aug_recv=aug_recv, n_out=n_out, n_in=n_in, out_row=out_row, flag_rows=flag_rows, in_map=in_map)
-        if self._vote_out is None or self._vote_out.shape[0] < n_out:
-            self._vote_out = torch.empty((int(n_out * 1.25) + 64, 4), dtype=torch.float64, device=dev)
-        if self._vote_in is None or self._vote_in.shape[0] < n_in:
-            self._vote_in = torch.empty((int(n_in * 1.25) + 64, 4), dtype=torch.float64, device=dev)
-
-    def update_ghosts_with_vote(self, d_flag):
-        """Ghost positions and the rebuild vote in one exchange (see _build_vote_plan); afterwards the word at
-        d_flag holds the maximum of the flag words of all ranks."""
-        A, vp, m = self.arrays, self.vote_plan, _abi()
-        self.n_vote_exchanges += 1
-        a = m.PackVoteArgs()
-        a.pack.d_out, a.pack.d_pos = self._vote_out.data_ptr(), A.pos.data_ptr()
-        a.pack.d_send_idx, a.pack.d_send_shift_id = self.send_idx32.data_ptr(), self.send_dir.data_ptr()
-        a.pack.d_shift_table, a.pack.n_send = self.shift_table.data_ptr(), int(self.send_idx32.numel())
-        a.d_out_row, a.d_flag_word = vp["out_row"].data_ptr(), d_flag
-        a.d_flag_rows, a.n_flag_rows = vp["flag_rows"].data_ptr(), int(vp["flag_rows"].numel())
-        m.check(m.lib.hmd_pack_ghost_positions_vote(ctypes.byref(a), self._stream), "hmd_pack_ghost_positions_vote")
-        self._a2a(self._vote_in[:vp["n_in"]], self._vote_out[:vp["n_out"]], vp["aug_recv"], vp["aug_send"])
-        u = m.UnpackVoteArgs()
-        u.d_in, u.d_map, u.n_rows = self._vote_in.data_ptr(), vp["in_map"].data_ptr(), vp["n_in"]
-        u.d_ghost_pos, u.d_flag_word = A.pos.data_ptr() + 32 * A.N, d_flag
-        m.check(m.lib.hmd_unpack_ghost_positions(ctypes.byref(u), self._stream), "hmd_unpack_ghost_positions")
+        A.rtag[A.tag[:n_all].to(torch.int64)] = torch.arange(n_all, dtype=torch.int32, device=self.device)
 
     def pack(self):
         A = self.arrays
-        if self.pack_fn is not None:
-            return self.pack_fn(self)
         buf = A.pos[self.send_idx]
         buf[:, :3] += self.send_shift
         return buf
@@ -743,129 +456,123 @@ class ParticleExchange:
 
     def any_rank(self, local):
         if self._vote is None:
-            self._vote = torch.zeros(1, dtype=torch.int32, device="cpu" if self._stage else self.device)
+            self._vote = torch.zeros(1, dtype=torch.int32, device=self.device)
         t = self._vote
         t.fill_(1 if local else 0)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.dd.group)
         return bool(t.item())
 
 
-class Communicator(_cpp.Communicator):
-    """The object the C++ host classes call (interface of hoomd/Communicator.h:166-232)."""
+class TorchTransport(getattr(_cpp, "ExchangeTransport", object)):
+    """The message-passing layer under the C++ communicator: device buffers go to ``torch.distributed``
+    (``all_to_all_single`` / ``all_reduce``; backend "nccl" = RCCL moves them GPU to GPU).  With the gloo backend (tests
+    and rehearsals with several ranks on one GPU) buffers are staged through pinned host memory with asynchronous copies
+    on the stream the exchange kernels run on."""
 
-    def __init__(self, decomposition, sysdef):
-        _cpp.Communicator.__init__(self)
-        self.dd = decomposition
-        self.sysdef = sysdef
-        self.pdata = sysdef.getParticleData()
-        self.nlists = []
-        self._force_migrate = True
-        self._pack_buf = None
-        self._flag_view = None
-        self._vote = None
-        self._in_communicate = False
-        self._ghosts_fresh = False
-        self._side = None
-        self.use_vote_rows = os.environ.get("HOOMD_AMD_VOTE_ROWS", "1") != "0"
-        self.exchange = ParticleExchange(decomposition, PDataArrays(self.pdata), pack_fn=self._pack_kernel)
+    def __init__(self, group, device):
+        super().__init__()
+        self.group = group
+        self.device = device
+        self.stage = dist.get_backend(group) == "gloo"
+        self._views = {}
+        self._streams = {}
+        self._pinned = {}
+        self._empty = torch.zeros(0, dtype=torch.uint8, device=device)
+        self._vote = torch.zeros(1, dtype=torch.int32, device="cpu" if self.stage else device)
+        self.side = None  # (stream handle, torch stream) of the last exchange queued on a stream of its own
 
-    def _pack_kernel(self, ex):
-        from . import _abi
-        n = int(ex.send_idx32.numel())
-        if self._pack_buf is None or self._pack_buf.shape[0] < n:
-            self._pack_buf = torch.empty((int(n * 1.25) + 64, 4), dtype=torch.float64, device=ex.device)
-        out = self._pack_buf[:n]
-        if n:
-            a = _abi.PackPosArgs()
-            a.d_out = out.data_ptr()
-            a.d_pos = ex.arrays.pos.data_ptr()
-            a.d_send_idx = ex.send_idx32.data_ptr()
-            a.d_send_shift_id = ex.send_dir.data_ptr()
-            a.d_shift_table = ex.shift_table.data_ptr()
-            a.n_send = n
-            _abi.check(_abi.lib.hmd_pack_ghost_positions(ctypes.byref(a), ex._stream), "hmd_pack_ghost_positions")
-        return out
+    def _view(self, ptr, nbytes, dtype=torch.uint8):
+        if nbytes == 0:
+            return self._empty
+        key = (ptr, nbytes, dtype)
+        v = self._views.get(key)
+        if v is None:
+            if len(self._views) > 512:
+                self._views.clear()
+            n = nbytes // dtype.itemsize
+            v = torch.as_tensor(_DevMem(ptr, (n,), {torch.uint8: "|u1", torch.int32: "<i4"}[dtype]), device=self.device)
+            self._views[key] = v
+        return v
 
-    # -- interface called from C++ --
-    def getGhostLayerMaxWidth(self):
-        w = 0.0
-        for nl in self.nlists:
-            if nl._cpp_obj is not None:
-                w = max(w, nl._cpp_obj.getGhostLayerWidth())
-        return w
+    def _pinned_like(self, name, t):
+        nbytes = t.numel() * t.element_size()
+        buf = self._pinned.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
+            self._pinned[name] = buf
+        return buf[:nbytes].view(t.dtype).view(t.shape)
 
-    def forceMigrate(self):
-        self._force_migrate = True
+    def _on(self, stream):
+        if not stream:
+            return contextlib.nullcontext()
+        s = self._streams.get(stream)
+        if s is None:
+            s = torch.cuda.ExternalStream(stream)
+            self._streams[stream] = s
+        self.side = (stream, s)
+        return torch.cuda.stream(s)
+
+    def allToAll(self, d_send, send_rows, d_recv, recv_rows, row_bytes, stream):
+        in_splits = [r * row_bytes for r in send_rows]
+        out_splits = [r * row_bytes for r in recv_rows]
+        inp, out = self._view(d_send, sum(in_splits)), self._view(d_recv, sum(out_splits))
+        with self._on(stream):
+            if self.stage:
+                cur = torch.cuda.current_stream(self.device)
+                hin, hout = self._pinned_like("in", inp), self._pinned_like("out", out)
+                hin.copy_(inp, non_blocking=True)
+                cur.synchronize()
+                dist.all_to_all_single(hout, hin, out_splits, in_splits, group=self.group)
+                out.copy_(hout, non_blocking=True)
+                cur.synchronize()  # the buffers are reused by the next call
+            else:
+                dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def allReduceMaxWord(self, d_word, stream):
+        word = self._view(d_word, 4, torch.int32)
+        with self._on(stream):
+            if self.stage:
+                cur = torch.cuda.current_stream(self.device)
+                v = self._pinned_like("vote", word)
+                v.copy_(word, non_blocking=True)
+                cur.synchronize()
+                dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+                word.copy_(v, non_blocking=True)
+                cur.synchronize()
+            else:
+                dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
 
     def anyRank(self, local):
-        return self.exchange.any_rank(bool(local))
+        self._vote.fill_(1 if local else 0)
+        dist.all_reduce(self._vote, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(self._vote.item())
 
-    def beginRebuildVote(self, d_flag, checkn, stream=0):
-        """Device-side rebuild vote: the flag word of the distance check (the number of the last check that
-        found the list stale, the same count on every rank) is MAX-reduced in place over all ranks, with no
-        host round trip between the distance check and the reduction.
-        On the (common) steps where only ghost positions need refreshing the halo exchange is queued first,
-        so one wait covers both and work predicated on the vote can be queued behind it.
-        stream: HIP stream to queue all of this on (0: the default stream)."""
-        if not stream:
-            return self._begin_rebuild_vote(d_flag, checkn)
-        if self._side is None or self._side[0] != stream:
-            self._side = (stream, torch.cuda.ExternalStream(stream))
-        ex = self.exchange
-        ex._stream = stream
-        try:
-            with torch.cuda.stream(self._side[1]):
-                return self._begin_rebuild_vote(d_flag, checkn)
-        finally:
-            ex._stream = None
 
-    def _begin_rebuild_vote(self, d_flag, checkn):
-        ex = self.exchange
-        if self._flag_view is None or self._flag_view[0] != d_flag:
-            self._flag_view = (d_flag, torch.as_tensor(_DevMem(d_flag, (1,), "<i4"), device=ex.device))
-        word = self._flag_view[1]
-        if self._in_communicate and not self._force_migrate and not self._ghosts_fresh:
-            self._ghosts_fresh = True
-            if ex.vote_plan is not None and self.use_vote_rows:
-                ex.update_ghosts_with_vote(int(d_flag))
-                self._vote = (word, int(checkn))
-                return int(d_flag)
-            ex.update_ghosts()
-        if ex._stage:  # gloo rehearsal on device memory: reduce through a pinned host word
-            stream = torch.cuda.current_stream(ex.device)
-            v = ex._pinned_like("vote", word)
-            v.copy_(word, non_blocking=True)
-            stream.synchronize()
-            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.dd.group)
-            word.copy_(v, non_blocking=True)
-            stream.synchronize()
-        else:
-            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.dd.group)
-        self._vote = (word, int(checkn))
-        return int(d_flag)
+class Communicator:
+    """Holder of the C++ communicator (``_cpp.CommunicatorGPU``, interface of hoomd/Communicator.h:166-232: migration,
+    ghost exchange, per-step ghost update, rebuild vote) and of its transport."""
 
-    def endRebuildVote(self):
-        word, checkn = self._vote
-        return int(word.item()) == checkn
+    def __init__(self, decomposition, sysdef):
+        dd = decomposition
+        self.dd = dd
+        self.sysdef = sysdef
+        device = torch.device("cuda", torch.cuda.current_device())
+        self.transport = TorchTransport(dd.group, device)
+        self.cpp = _cpp.CommunicatorGPU(sysdef, self.transport, dd.rank, dd.world, [int(g) for g in dd.grid], [float(v) for v in dd.glo],
+                                        [float(v) for v in dd.gL])
+        self.cpp.setUseVoteRows(os.environ.get("HOOMD_AMD_VOTE_ROWS", "1") != "0")
+        self.cpp.setFixedMigrate(os.environ.get("HOOMD_AMD_FIXED_MIGRATE", "1") != "0")
+        self.cpp.setMigrateSlotRows(int(os.environ.get("HOOMD_AMD_MIGRATE_SLOT_ROWS", "1024")))
+        self.nlists = []
 
-    def communicate(self, timestep):
-        ex = self.exchange
-        ex.arrays.refresh()
-        migrate = self._force_migrate
-        self._ghosts_fresh = False
-        self._in_communicate = True
-        try:
-            for nl in self.nlists:
-                if nl._cpp_obj is not None and nl._cpp_obj.peekUpdate(timestep):
-                    migrate = True
-        finally:
-            self._in_communicate = False
-        if migrate:
-            self._force_migrate = False
-            ex.migrate()
-            # on every rank, whether or not its own particle set changed: the forced-update state of
-            # the neighbor list must stay identical across ranks or their collective calls diverge
-            self.pdata.notifyParticleSort()
-            ex.exchange_ghosts(self.getGhostLayerMaxWidth())
-        elif not self._ghosts_fresh:
-            ex.update_ghosts()
+    def add_nlist(self, nlist):
+        self.nlists.append(nlist)
+        self.cpp.addNeighborList(nlist._cpp_obj)
+
+    # statistics of the exchange (tests, bench)
+    n_migrated_out = property(lambda self: self.cpp.n_migrated_out)
+    n_migrated_in = property(lambda self: self.cpp.n_migrated_in)
+    n_vote_exchanges = property(lambda self: self.cpp.n_vote_exchanges)
+    n_count_exchanges = property(lambda self: self.cpp.n_count_exchanges)
+    fixed_migrate = property(lambda self: self.cpp.fixed_migrate)
+    migrate_slot_rows = property(lambda self: self.cpp.migrate_slot_rows)

@@ -440,6 +440,15 @@ def gather_rows(src, order):
     return out
 
 
+def sort_keys(keys, key_bits=64):
+    """Ascending sort of int64 keys whose low key_bits bits are significant (hmd_sort_keys)."""
+    out = torch.empty_like(keys)
+    n = keys.numel()
+    ws = torch.empty(max(int(_abi.lib.hmd_sort_keys_workspace_bytes(n)), 1), dtype=torch.uint8, device=keys.device)
+    check(_abi.lib.hmd_sort_keys(ptr(keys), ptr(out), n, key_bits, ptr(ws), ws.numel(), _stream(keys)), "hmd_sort_keys")
+    return out
+
+
 def build_rtag(tag):
     rtag = torch.zeros_like(tag)
     check(_abi.lib.hmd_build_rtag(ptr(rtag), ptr(tag), tag.numel(), _stream(tag)), "hmd_build_rtag")

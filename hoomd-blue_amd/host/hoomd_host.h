@@ -1612,6 +1612,124 @@ struct ScopedKernelTimer
         }
     };
 
+// ---------------------------------------------------------------------------------------------
+// CommunicatorGPU (hoomd/Communicator.h:166-232, hoomd/CommunicatorGPU.cc): migration, ghost exchange, per-step ghost
+// update and the rebuild vote, driven from C++.  The message-passing layer is an interface: the production object
+// hands the device buffers to torch.distributed (RCCL), the test object stages them through gloo.
+// ---------------------------------------------------------------------------------------------
+class ExchangeTransport
+    {
+    public:
+    virtual ~ExchangeTransport() { }
+    //! All-to-all of rows of row_bytes bytes: send_rows[r] rows go to rank r (consecutive in d_send by rank),
+    //! recv_rows[r] rows arrive from rank r in d_recv; queued on `stream` (0: the default stream).  Every rank calls.
+    virtual void allToAll(uintptr_t d_send, const std::vector<unsigned int>& send_rows, uintptr_t d_recv, const std::vector<unsigned int>& recv_rows,
+                          unsigned int row_bytes, uintptr_t stream)
+        = 0;
+    //! in-place maximum over all ranks of one 32-bit device word, queued on `stream`
+    virtual void allReduceMaxWord(uintptr_t d_word, uintptr_t stream) = 0;
+    //! logical OR of a host flag over all ranks
+    virtual bool anyRank(bool local) = 0;
+    };
+
+class CommunicatorGPU : public Communicator
+    {
+    public:
+    //! grid: domains per direction, rank = (k * grid[1] + j) * grid[0] + i; glo / gL: the global box
+    CommunicatorGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ExchangeTransport> transport, unsigned int rank, unsigned int world,
+                    std::array<unsigned int, 3> grid, std::array<double, 3> glo, std::array<double, 3> gL);
+    void addNeighborList(std::shared_ptr<NeighborListGPUBinned> nl)
+        {
+        m_nlists.push_back(nl);
+        }
+    void communicate(uint64_t timestep) override;
+    void forceMigrate() override
+        {
+        m_force_migrate = true;
+        }
+    Scalar getGhostLayerMaxWidth() const override;
+    bool anyRank(bool local) override
+        {
+        return m_transport->anyRank(local);
+        }
+    uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn, uintptr_t stream) override;
+    bool endRebuildVote() override;
+
+    //! hoomd/Communicator.cc migrateParticles; true when this rank's particle set changed
+    bool migrateParticles();
+    //! hoomd/Communicator.cc exchangeGhosts
+    void exchangeGhosts(Scalar r_ghost);
+    //! hoomd/Communicator.cc beginUpdateGhosts / finishUpdateGhosts
+    void updateGhosts(hipStream_t stream);
+    void setUseVoteRows(bool b)
+        {
+        m_use_vote_rows = b;
+        }
+    void setFixedMigrate(bool b)
+        {
+        m_fixed_migrate = b && m_all_peers;
+        }
+    void setMigrateSlotRows(unsigned int n)
+        {
+        m_mig_slot_rows = std::max(n, 1u);
+        }
+    // statistics
+    uint64_t n_migrated_out = 0, n_migrated_in = 0, n_vote_exchanges = 0, n_count_exchanges = 0;
+    bool usesFixedMigrate() const
+        {
+        return m_fixed_migrate;
+        }
+    unsigned int getMigrateSlotRows() const
+        {
+        return m_mig_slot_rows;
+        }
+
+    private:
+    hmd_pdata_arrays_t pdataArrays() const;
+    void sortKeys(DeviceArray<unsigned long long>& keys, unsigned int n, unsigned int key_bits);
+    void updateGhostsWithVote(unsigned int* d_flag, hipStream_t stream);
+    void buildVotePlan();
+    unsigned int rankAt(int i, int j, int k) const;
+
+    std::shared_ptr<SystemDefinition> m_sysdef;
+    std::shared_ptr<ParticleData> m_pdata;
+    std::shared_ptr<ExchangeTransport> m_transport;
+    std::vector<std::weak_ptr<NeighborListGPUBinned>> m_nlists;
+    unsigned int m_rank, m_world;
+    std::array<unsigned int, 3> m_grid, m_coords;
+    std::array<double, 3> m_glo, m_gL;
+    std::array<bool, 3> m_decomposed;
+    bool m_force_migrate = true, m_in_communicate = false, m_ghosts_fresh = false, m_use_vote_rows = true;
+    bool m_all_peers = false, m_fixed_migrate = false, m_have_vote_plan = false;
+    // one entry per direction towards a neighbor domain, sorted by destination rank
+    std::vector<unsigned int> m_dir_dest;
+    DeviceArray<unsigned int> m_dir_mask;
+    DeviceArray<Scalar3> m_shift_table;
+    // migration
+    DeviceArray<int> m_mig_dest;
+    DeviceArray<unsigned int> m_mig_counters, m_scratch;
+    DeviceArray<unsigned long long> m_mig_keys, m_keys_sorted;
+    DeviceArray<long long> m_mig_out, m_mig_in;
+    DeviceArray<unsigned char> m_sort_ws;
+    unsigned int m_mig_slot_rows = 1024;
+    // ghost layer
+    DeviceArray<double> m_r_ghost;
+    double m_r_ghost_value = -1;
+    DeviceArray<unsigned long long> m_keys;
+    DeviceArray<unsigned int> m_send_counters, m_send_idx, m_count_out, m_count_in;
+    DeviceArray<unsigned char> m_send_dir;
+    DeviceArray<Scalar4> m_init_out, m_init_in, m_pack_buf, m_vote_out, m_vote_in;
+    unsigned int m_n_send = 0;
+    std::vector<unsigned int> m_send_rows, m_recv_rows, m_aug_send, m_aug_recv;
+    DeviceArray<unsigned int> m_out_row, m_flag_rows;
+    DeviceArray<int> m_in_map;
+    unsigned int m_n_out = 0, m_n_in = 0;
+    WordReadback m_readback;
+    // the vote in flight
+    unsigned int* m_vote_word = nullptr;
+    unsigned int m_vote_checkn = 0;
+    };
+
 // A plugin built outside the tree holds the layout of the classes above in its own objects (their inline accessors,
 // the offsets of the members its templates touch).  Sizes of the classes a pair potential reaches into, folded into
 // one number: the plugin computes it from the headers it was compiled with, the core module from its own, and the

@@ -99,37 +99,25 @@ py::dict take_snapshot(const ParticleData& pdata)
     return d;
     }
 
-//! trampoline: the halo exchange lives in Python (torch.distributed / RCCL)
-class PyCommunicator : public Communicator
+//! trampoline: the message-passing layer lives in Python (torch.distributed: RCCL in production, gloo in tests)
+class PyExchangeTransport : public ExchangeTransport
     {
     public:
-    using Communicator::Communicator;
-    void communicate(uint64_t timestep) override
+    using ExchangeTransport::ExchangeTransport;
+    void allToAll(uintptr_t d_send, const std::vector<unsigned int>& send_rows, uintptr_t d_recv, const std::vector<unsigned int>& recv_rows,
+                  unsigned int row_bytes, uintptr_t stream) override
         {
-        PYBIND11_OVERRIDE_PURE(void, Communicator, communicate, timestep);
+        PYBIND11_OVERRIDE_PURE(void, ExchangeTransport, allToAll, d_send, send_rows, d_recv, recv_rows, row_bytes, stream);
         }
-    void forceMigrate() override
+    void allReduceMaxWord(uintptr_t d_word, uintptr_t stream) override
         {
-        PYBIND11_OVERRIDE_PURE(void, Communicator, forceMigrate);
-        }
-    Scalar getGhostLayerMaxWidth() const override
-        {
-        PYBIND11_OVERRIDE_PURE(Scalar, Communicator, getGhostLayerMaxWidth);
+        PYBIND11_OVERRIDE_PURE(void, ExchangeTransport, allReduceMaxWord, d_word, stream);
         }
     bool anyRank(bool local) override
         {
-        PYBIND11_OVERRIDE_PURE(bool, Communicator, anyRank, local);
-        }
-    uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn, uintptr_t stream) override
-        {
-        PYBIND11_OVERRIDE(uintptr_t, Communicator, beginRebuildVote, d_flag, checkn, stream);
-        }
-    bool endRebuildVote() override
-        {
-        PYBIND11_OVERRIDE(bool, Communicator, endRebuildVote);
+        PYBIND11_OVERRIDE_PURE(bool, ExchangeTransport, anyRank, local);
         }
     };
-
     } // namespace
 
 PYBIND11_MODULE(_hoomd_amd, m)
@@ -215,14 +203,29 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property_readonly("net_force_ptr", [](ParticleData& p) { return (uintptr_t)p.netForceForIntegration(); })
         .def("rebuildRTag", [](ParticleData& p) { abiCheck(hmd_build_rtag(p.rtag(), p.tag(), p.getN(), nullptr), "hmd_build_rtag"); });
 
-    py::class_<Communicator, PyCommunicator, std::shared_ptr<Communicator>>(m, "Communicator")
-        .def(py::init<>())
+    py::class_<Communicator, std::shared_ptr<Communicator>>(m, "Communicator")
         .def("communicate", &Communicator::communicate)
         .def("forceMigrate", &Communicator::forceMigrate)
         .def("getGhostLayerMaxWidth", &Communicator::getGhostLayerMaxWidth)
         .def("anyRank", &Communicator::anyRank)
         .def("beginRebuildVote", &Communicator::beginRebuildVote)
         .def("endRebuildVote", &Communicator::endRebuildVote);
+    py::class_<ExchangeTransport, PyExchangeTransport, std::shared_ptr<ExchangeTransport>>(m, "ExchangeTransport").def(py::init<>());
+    py::class_<CommunicatorGPU, Communicator, std::shared_ptr<CommunicatorGPU>>(m, "CommunicatorGPU")
+        .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<ExchangeTransport>, unsigned int, unsigned int, std::array<unsigned int, 3>,
+                      std::array<double, 3>, std::array<double, 3>>())
+        .def("addNeighborList", &CommunicatorGPU::addNeighborList)
+        .def("migrateParticles", &CommunicatorGPU::migrateParticles)
+        .def("exchangeGhosts", &CommunicatorGPU::exchangeGhosts)
+        .def("setUseVoteRows", &CommunicatorGPU::setUseVoteRows)
+        .def("setFixedMigrate", &CommunicatorGPU::setFixedMigrate)
+        .def("setMigrateSlotRows", &CommunicatorGPU::setMigrateSlotRows)
+        .def_property_readonly("fixed_migrate", &CommunicatorGPU::usesFixedMigrate)
+        .def_property_readonly("migrate_slot_rows", &CommunicatorGPU::getMigrateSlotRows)
+        .def_readonly("n_migrated_out", &CommunicatorGPU::n_migrated_out)
+        .def_readonly("n_migrated_in", &CommunicatorGPU::n_migrated_in)
+        .def_readonly("n_vote_exchanges", &CommunicatorGPU::n_vote_exchanges)
+        .def_readonly("n_count_exchanges", &CommunicatorGPU::n_count_exchanges);
 
     py::class_<SystemDefinition, std::shared_ptr<SystemDefinition>>(m, "SystemDefinition")
         .def(py::init([](py::dict snap, const BoxDim& box, unsigned int ndim, unsigned int seed, unsigned int n_global)

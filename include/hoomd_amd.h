@@ -633,6 +633,14 @@ typedef struct
     } hmd_unpack_vote_args_t;
 int hmd_unpack_ghost_positions(const hmd_unpack_vote_args_t* args, void* stream);
 
+/* Ascending sort of 64-bit keys, of which only the low key_bits bits are significant (the others must be equal in
+   all keys).  The send lists of the exchange are built as unordered keys (destination << 32 | particle index);
+   sorted they are grouped by destination in a reproducible order (the reference sorts with thrust behind its
+   CachedAllocator, hoomd/CommunicatorGPU.cu:374-520).  d_keys_in and d_keys_out must differ. */
+size_t hmd_sort_keys_workspace_bytes(unsigned int n);
+int hmd_sort_keys(const unsigned long long* d_keys_in, unsigned long long* d_keys_out, unsigned int n, unsigned int key_bits,
+                  void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* The per-particle arrays a migrating particle takes along (pdata_element, hoomd/ParticleData.h:153-175). */
 typedef struct
     {

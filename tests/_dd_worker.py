@@ -68,7 +68,7 @@ def main():
 
         def watchdog():
             if not done.wait(25.0):
-                side = dd.communicator._side
+                side = dd.communicator.transport.side
                 print(f"[watchdog rank {rank}] step {sim.timestep}: default stream idle={torch.cuda.default_stream().query()}, "
                       f"exchange stream idle={side[1].query() if side else None}", flush=True)
         threading.Thread(target=watchdog, daemon=True).start()
@@ -82,9 +82,9 @@ def main():
     stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds),
                  overlapped=int(cell._cpp_obj.num_overlapped))
     if dd is not None:
-        ex = dd.communicator.exchange
+        ex = dd.communicator
         stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges),
-                     fixed_migrate=int(ex._fixed_migrate), slot_rows=int(ex._mig_slot_rows))
+                     fixed_migrate=int(ex.fixed_migrate), slot_rows=int(ex.migrate_slot_rows), count_exchanges=int(ex.n_count_exchanges))
         allstats = [None] * world
         dist.all_gather_object(allstats, stats)
     else:

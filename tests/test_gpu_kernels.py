@@ -913,3 +913,15 @@ def test_ghost_exchange_helper_kernels(K, A):
         assert o.cpu().tolist()[:sum(send_c)] == out_row and f.cpu().tolist() == flag_rows and im.cpu().tolist() == in_map
     a.n_ranks = 65
     assert A.lib.hmd_vote_plan(C.byref(a), None) == A.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("n,bits", [(0, 37), (1, 37), (777, 37), (200000, 37), (5000, 64), (4096, 33)])
+def test_sort_keys(K, A, n, bits):
+    """hmd_sort_keys: the send-list keys (destination << 32 | particle index) in ascending order."""
+    rng = np.random.default_rng(n + bits)
+    if bits == 64:
+        keys = rng.integers(0, 2**62, n, dtype=np.int64)
+    else:
+        keys = (rng.integers(0, 2**(bits - 32), n, dtype=np.int64) << 32) | rng.integers(0, 2**21, n, dtype=np.int64)
+    out = K.sort_keys(torch.from_numpy(keys).cuda(), bits).cpu().numpy()
+    assert np.array_equal(out, np.sort(keys))
