@@ -160,10 +160,8 @@ def main():
         thermostat = hoomd.md.methods.thermostats.Bussi(kT=1.0)
         sim, cell, lj, method = lj_liquid.make_ka_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
     elif args.workload == "kg":
-        if world > 1:
-            raise SystemExit("the bonded workload runs on one GPU")
         thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.0, tau=0.5)
-        sim, cell, lj, fene, method = lj_liquid.make_kg_simulation(hoomd, n, thermostat=thermostat)
+        sim, cell, lj, fene, method = lj_liquid.make_kg_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
     else:
         thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
         sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)

@@ -26,8 +26,8 @@ class State:
             self._sysdef = decomposition._make_sysdef(snapshot, cbox, self._ndim, sim.seed)
         self._pdata = self._sysdef.getParticleData()
         if snapshot.bonds.N or snapshot.bonds.types:
-            if decomposition is not None:
-                raise NotImplementedError("bonds under domain decomposition are outside this backend's scope")
+            # Under domain decomposition every rank keeps the whole (static) bond topology keyed by tag; the per-rank
+            # table by local index is rebuilt from it after every migration (partners are owned or ghost particles).
             self._sysdef.setBonds(*snapshot._bonds_to_args())
 
     @property

@@ -1,5 +1,12 @@
 // bonds.cc -- BondData (hoomd/BondedGroupData.{h,cc}, bonds only) and the FENE + WCA bond force
 // (hoomd/md/PotentialBond.h, hoomd/md/PotentialBondGPU.h).
+//
+// Under domain decomposition the reference migrates bonds with their particles and marks bond partners for the ghost
+// exchange (hoomd/CommunicatorGPU.cc:718-1618).  Here the topology is static data: every rank holds the whole table
+// keyed by tag (8 bytes per bond end: 128 MB for 8 million beads with two bonds each, out of 288 GB), and the table by
+// local index is rebuilt from it with one kernel after every migration; a partner is found through rtag among the
+// owned particles and the ghosts, which the ghost layer of the neighbor list (r_cut + buffer) already holds for
+// every bond shorter than that.  Each rank evaluates a bond for the ends it owns, as it does for pairs.
 #include "hoomd_host.h"
 
 #include <algorithm>
@@ -82,7 +89,8 @@ void BondData::update()
 void BondData::checkComplete()
     {
     if (m_flags.get()[0])
-        throw std::runtime_error("Error: a bond is incomplete (one of its particles is not on this rank)");
+        throw std::runtime_error("Error: a bond is incomplete: one of its particles is neither owned by this rank nor in its ghost layer (bonds longer "
+                                 "than the ghost layer, r_cut + buffer of the neighbor list, cannot be followed)");
     }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,8 +99,6 @@ PotentialBondFENEGPU::PotentialBondFENEGPU(std::shared_ptr<SystemDefinition> sys
     {
     if (!m_bonds)
         throw std::runtime_error("bond.fene: the system defines no bonds or bond types");
-    if (sysdef->isDomainDecomposed())
-        throw std::runtime_error("bond forces are not available under domain decomposition in this backend");
     hmd_fene_params_t zero;
     std::memset(&zero, 0, sizeof(zero));
     m_params.assign(std::max(m_bonds->getNTypes(), 1u), zero);

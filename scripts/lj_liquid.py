@@ -102,12 +102,15 @@ def make_kg_snapshot(hoomd, n, chain_length=32, kT=1.0, seed=1234, jitter=0.02):
     return snap
 
 
-def make_kg_simulation(hoomd, n, chain_length=32, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200):
+def make_kg_simulation(hoomd, n, chain_length=32, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200, decomposition=None):
     """WCA pair force (LJ cut at 2^(1/6), shifted) + FENE/WCA bonds (k = 30, r0 = 1.5), bonded pairs excluded from
     the pair force: the Kremer-Grest bead-spring melt."""
     snap = make_kg_snapshot(hoomd, n, chain_length, kT, seed)
     sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=seed)
-    sim.create_state_from_snapshot(snap)
+    if decomposition is not None:
+        sim.create_state_from_snapshot(snap, domain_decomposition=decomposition)
+    else:
+        sim.create_state_from_snapshot(snap)
     cell = hoomd.md.nlist.Cell(buffer=buffer, exclusions=("bond",))
     wca = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.0 ** (1.0 / 6.0), mode="shift")
     wca.params[("A", "A")] = dict(epsilon=1.0, sigma=1.0)

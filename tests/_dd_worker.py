@@ -19,6 +19,17 @@ import torch.distributed as dist
 faulthandler.register(signal.SIGUSR1, all_threads=True, chain=False)
 
 
+def build_kg(hoomd, decomposition, n, steps, sorter):
+    """Bead-spring melt: WCA pairs with bond exclusions + FENE bonds, chains of 8 along x."""
+    import lj_liquid
+    sim, cell, wca, fene, _ = lj_liquid.make_kg_simulation(hoomd, n, chain_length=8, seed=5, sorter_period=7, decomposition=decomposition)
+    if not sorter:
+        sim.operations.tuners.clear()
+    thermo = hoomd.md.compute.ThermodynamicProperties(hoomd.filter.All())
+    sim.operations.computes.append(thermo)
+    return sim, cell, wca, thermo
+
+
 def build(hoomd, decomposition, n, steps, sorter):
     import lj_liquid
     snap = lj_liquid.make_snapshot(hoomd, n, kT=1.5, seed=11)
@@ -51,6 +62,7 @@ def main():
     n = tuple(int(v) for v in sys.argv[8:11])
     steps = int(sys.argv[11])
     sorter = bool(int(sys.argv[12]))
+    workload = sys.argv[13] if len(sys.argv) > 13 else "lj"
     import hoomd_amd as hoomd
     dd = None
     if world > 1:
@@ -59,7 +71,7 @@ def main():
         from hoomd_amd import comm
         dd = comm.DomainDecomposition(grid=grid)
     torch.cuda.set_device(0)
-    sim, cell, lj, thermo = build(hoomd, dd, n, steps, sorter)
+    sim, cell, lj, thermo = (build_kg if workload == "kg" else build)(hoomd, dd, n, steps, sorter)
     sim.run(0)
     if dd is not None:
         # a stuck run says which stream holds unfinished work before the launcher's limit ends it

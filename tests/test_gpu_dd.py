@@ -76,6 +76,26 @@ def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, 
         assert o.stats()["num_builds"] == b["builds"][0]
 
 
+@pytest.mark.parametrize("world,grid,sorter", [(2, (2, 1, 1), 0), (4, (2, 2, 1), 1), (8, (2, 2, 2), 1)])
+def test_bonded_melt_under_decomposition_matches_single_domain(tmp_path, world, grid, sorter):
+    """Bead-spring melt (WCA + FENE, bonded pairs excluded) on 2, 4 and 8 ranks against the single-domain run of the
+    same system: bonds and exclusions that cross sub-box faces, chains that migrate.  (The single-domain run is the
+    one tests/test_gpu_bonds_md.py checks against the CPU oracle.)"""
+    n, steps = (16, 12, 12), 240  # long enough for beads to cross sub-box faces from the lattice start
+    ref, out = str(tmp_path / "ref.npz"), str(tmp_path / "dd.npz")
+    launch("_dd_worker.py", 1, [1, 1, 1, ref] + list(n) + [steps, sorter, "kg"], timeout=60)
+    launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter, "kg"], timeout=90)
+    a, b = np.load(ref), np.load(out)
+    assert sum(b["N_local"]) == n[0] * n[1] * n[2] and all(g > 0 for g in b["n_ghosts"])
+    assert np.allclose(a["e0"], b["e0"], rtol=1e-11)
+    assert np.allclose(a["e1"], b["e1"], rtol=1e-7)
+    L = np.array(n) * np.array([0.97, 1.05, 1.05])
+    ua, ub = a["position"] + a["image"] * L, b["position"] + b["image"] * L
+    assert np.abs(ua - ub).max() < 1e-6
+    assert np.abs(a["velocity"] - b["velocity"]).max() < 1e-5
+    assert sum(b["migrated"]) > 0
+
+
 def test_one_rank_decomposition_over_rccl_at_production_priority():
     """The production transport and stream priority, as far as one GPU allows: one rank (nothing to exchange: the
     migration, ghost and vote collectives run empty), RCCL collectives on the high-priority exchange stream."""
