@@ -141,7 +141,7 @@ __device__ __forceinline__ pft_axis pft_axis_cell(int c, int dim, bool periodic)
     return r;
     }
 
-template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE>
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false>
 __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params,
                             pft_launch_t lp)
@@ -160,9 +160,22 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
     pft_home_t* s_home = reinterpret_cast<pft_home_t*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES);
     if ((unsigned int)(size_t)(__attribute__((address_space(3))) void*)txyz != 0u)
         __builtin_trap(); // the toolchain placed something before the dynamic LDS
-    // One thread reads the predicate word for the whole workgroup (another stream may be raising it at this
-    // very moment: the rebuild vote of other ranks arriving; a workgroup must not split over it); the others
-    // learn it behind the barrier that follows the set-up below.
+    // Launches over the whole grid are queued behind whatever writes the predicate word, on the same stream: the word
+    // is final, every wave reads it for itself and a switched-off launch ends here, before any load is issued.
+    if (a.d_skip_flag && a.block_window_mode == 0)
+        {
+        const unsigned int word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (word == a.skip_value)
+            {
+            if (a.d_published && blockIdx.x == 0 && threadIdx.x == 0)
+                __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+            }
+        }
+    // Launches over a window of blocks run beside the exchange: one thread reads the predicate word for the whole
+    // workgroup (another stream may be raising it at this very moment: the rebuild vote of other ranks arriving; a
+    // workgroup must not split over it); the others learn it behind the barrier that follows the set-up below.
     if (a.d_skip_flag && threadIdx.x == 0)
         {
         const unsigned int word = __hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -432,6 +445,22 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
         pf_accum acc;
         const double xi = txyz[lh], yi = txyz[lh + 32], zi = txyz[lh + 64];
         const unsigned int ti = SINGLE_TYPE ? 0u : (unsigned int)ttype[lh];
+        // Two particle types: the two parameter sets a pair with this home particle can have sit in registers, chosen
+        // per neighbor by its type byte -- one LDS read per pair besides the coordinates instead of four in a
+        // dependent chain (type, then the table row), which made the binary mixture LDS-bound.
+        param_t prm2[2];
+        double rc2[2] = {0.0, 0.0}, ro2[2] = {0.0, 0.0};
+        if (TWO_TYPES)
+            {
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++)
+                {
+                prm2[tj] = s_params[tj * 2 + ti];
+                rc2[tj] = s_rcutsq[tj * 2 + ti];
+                if (SHIFT == 2)
+                    ro2[tj] = s_ronsq[tj * 2 + ti];
+                }
+            }
         // coordinates of the four neighbors of one row chunk, read from the tile
         struct quad
             {
@@ -471,6 +500,16 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                     ronsq = ronsq0;
                     prm = &p0;
                     }
+                else if (TWO_TYPES)
+                    {
+                    const bool second = ttype[c.j[m] >> 3] != 0;
+                    rcutsq = second ? rc2[1] : rc2[0];
+                    if (SHIFT == 2)
+                        ronsq = second ? ro2[1] : ro2[0];
+                    const param_t sel = second ? prm2[1] : prm2[0];
+                    pf_pair<Ev, SHIFT, VIRIAL>(acc, xi - c.x[m], yi - c.y[m], zi - c.z[m], rcutsq, ronsq, sel, 0.0, 0.0);
+                    continue;
+                    }
                 else
                     {
                     const unsigned int tp = (unsigned int)ttype[c.j[m] >> 3] * a.ntypes + ti;
@@ -489,7 +528,7 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
 #ifdef HMD_PFT_NO_PIPE
         constexpr bool PIPELINED = false;
 #else
-        constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL);
+        constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL && !TWO_TYPES);
 #endif
         quad qa;
         if (PIPELINED)
@@ -593,10 +632,15 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
         tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>, lds);
         hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
         }
+    else if (a.ntypes == 2)
+        {
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        }
     else
         {
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false>, lds);
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
         }
     return hmd_launch_status();
     }
