@@ -479,7 +479,7 @@ __device__ __forceinline__ nl_pref_t nl_pref_thresholds(double rl, double rl2, d
     return t;
     }
 
-template<bool TILE, bool EXCL>
+template<bool TILE, bool EXCL, bool TWO, int MAXK>
 __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
                                                               unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
                                                               unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group,
@@ -499,10 +499,22 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
     double* s_shift = s_shift_all + 3 * 64 * wave;
     unsigned int* s_tileoff = s_tileoff_all + 64 * wave;
 
-    const double rc0 = a.d_r_cut[0];
-    const double rl0 = HMD_ADD(rc0, a.r_buff);
-    const double rl2 = (rc0 > 0.0) ? HMD_MUL(rl0, rl0) : -1.0;
-    const nl_pref_t pf = nl_pref_thresholds(rl0, rl2, wmax);
+    // One or two particle types (TWO): thresholds per type pair, [tj * 2 + ti].  As integers: lo1 = bits(lo) + 1 (0 for a
+    // pair that is switched off: no distance is a hit then), and one band for all pairs, the widest.
+    constexpr int NTP = TWO ? 4 : 1;
+    double rl2_tp[NTP];
+    unsigned int lo1_tp[NTP], band_all = 0;
+#pragma unroll
+    for (int tp = 0; tp < NTP; tp++)
+        {
+        const double rc = a.d_r_cut[tp];
+        const double rl = HMD_ADD(rc, a.r_buff);
+        rl2_tp[tp] = (rc > 0.0) ? HMD_MUL(rl, rl) : -1.0;
+        const nl_pref_t pf = nl_pref_thresholds(rl, rl2_tp[tp], wmax);
+        lo1_tp[tp] = pf.hi > 0.0f ? __float_as_uint(pf.lo) + 1u : 0u;
+        if (pf.hi > 0.0f)
+            band_all = max(band_all, __float_as_uint(pf.hi) - __float_as_uint(pf.lo));
+        }
 
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const unsigned int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -626,7 +638,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         {
         const unsigned int nh = min(n_home - hbase, 64u);
         double hx = 0, hy = 0, hz = 0;
-        unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0;
+        unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0, htype = 0;
         if (lane < nh)
             {
             const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
@@ -635,24 +647,27 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             hy = v.y;
             hz = v.z;
             hidx = hmd_double_as_uint(v.w);
+            if (TWO)
+                htype = a.d_cell_type_body[w].x & 1u;
             if (hidx < a.N)
-                hnmax = a.d_Nmax[0];
+                hnmax = a.d_Nmax[htype];
             }
         // origin of the fp32 coordinates: the slab's first home particle
         const double Ox = rl_d(hx, 0), Oy = rl_d(hy, 0), Oz = rl_d(hz, 0);
         const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
 
-        for (unsigned int pbase = 0; pbase < T; pbase += NL_MAXK * 64)
+        for (unsigned int pbase = 0; pbase < T; pbase += MAXK * 64)
             {
-            const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(NL_MAXK * 64)));
-            nl_v2f fx[NL_PAIRS], fy[NL_PAIRS], fz[NL_PAIRS];
-            unsigned int co[NL_MAXK]; // what a row stores for the candidate: tile slot or particle index
-            unsigned int cidx[(EXCL && TILE) ? NL_MAXK : 1]; // tile rows with exclusions: the candidate's particle index as well
+            const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(MAXK * 64)));
+            nl_v2f fx[(MAXK / 2)], fy[(MAXK / 2)], fz[(MAXK / 2)];
+            unsigned int co[MAXK]; // what a row stores for the candidate: tile slot or particle index
+            unsigned int cidx[(EXCL && TILE) ? MAXK : 1]; // tile rows with exclusions: the candidate's particle index as well
+            unsigned int ctbits = 0;                          // two types: bit c = type of this lane's candidate in slab c
             // Loads in two batches of six slabs: first every address of a batch (the searches run on LDS), then every
             // load, then the conversions -- two memory round trips per pass instead of one per slab.
-            constexpr int NL_BATCH = NL_MAXK / 2;
+            constexpr int NL_BATCH = MAXK / 2;
 #pragma unroll
-            for (int b0 = 0; b0 < NL_MAXK; b0 += NL_BATCH)
+            for (int b0 = 0; b0 < MAXK; b0 += NL_BATCH)
                 {
                 if ((unsigned int)(b0 * 64) >= Tp)
                     {
@@ -680,6 +695,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         w_[q] = cand_lookup(k, lo_[q]);
                     }
                 double2 vxy[NL_BATCH], vzw[NL_BATCH];
+                unsigned int vty[TWO ? NL_BATCH : 1];
 #pragma unroll
                 for (int q = 0; q < NL_BATCH; q++)
                     {
@@ -687,6 +703,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     const double2* src = reinterpret_cast<const double2*>(a.d_cell_xyzf + (w_[q] == 0xffffffffu ? 0u : w_[q]));
                     vxy[q] = src[0];
                     vzw[q] = src[1];
+                    if (TWO)
+                        vty[q] = a.d_cell_type_body[w_[q] == 0xffffffffu ? 0u : w_[q]].x;
                     }
 #pragma unroll
                 for (int q = 0; q < NL_BATCH; q++)
@@ -698,6 +716,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     co[c] = 0xffffffffu;
                     if (EXCL && TILE)
                         cidx[c] = w_[q] != 0xffffffffu ? hmd_double_as_uint(vzw[q].y) : 0xffffffffu;
+                    if (TWO && w_[q] != 0xffffffffu)
+                        ctbits |= (vty[q] & 1u) << c;
                     if (w_[q] != 0xffffffffu)
                         {
                         const unsigned int lo = lo_[q];
@@ -726,8 +746,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             // patterns order like the values, so t = bits(r32) - (bits(lo) + 1) is negative (top bit set) exactly for
             // r32 <= lo, and below `band` exactly for lo < r32 <= hi
             const unsigned int nslab = (Tp + 63u) / 64u;
-            const unsigned int lo1 = __float_as_uint(pf.lo) + 1u;
-            const unsigned int band = pf.hi > 0.0f ? __float_as_uint(pf.hi) - __float_as_uint(pf.lo) : 0u;
+            const unsigned int band = band_all;
             for (unsigned int i = sub; i < nh; i += wpc)
                 {
                 const unsigned int iu = __builtin_amdgcn_readfirstlane(i);
@@ -740,14 +759,20 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 const unsigned int nmax_i = rl_u(hnmax, iu);
                 const unsigned int cnt_old = rl_u(cnt, iu);
                 const unsigned int nmax_w = TILE ? min(nmax_i, tile_row_cap) : nmax_i;
+                // thresholds of this particle's type against candidates of type 0 and 1
+                const unsigned int ti = TWO ? rl_u(htype, iu) : 0u;
+                const unsigned int lo1 = TWO ? (ti ? lo1_tp[1] : lo1_tp[0]) : lo1_tp[0];
+                const unsigned int lo1_d = TWO ? ((ti ? lo1_tp[3] : lo1_tp[2]) - lo1) : 0u; // added for candidates of type 1
+                const double rl2 = TWO ? (ti ? rl2_tp[1] : rl2_tp[0]) : rl2_tp[0];
+                const double rl2_b = TWO ? (ti ? rl2_tp[3] : rl2_tp[2]) : rl2;
 
                 // ---- test phase: nothing but vector arithmetic.  Every lane collects one bit per slab (slab c ends up
                 // at bit nslab - 1 - c) and the smallest distance of any of its candidates from the undecided band. ----
                 unsigned int bits = 0, nearest = 0xffffffffu;
-                if (pf.hi > 0.0f)
+                if (band != 0u)
                     {
 #pragma unroll
-                    for (int s = 0; s < NL_PAIRS; s++)
+                    for (int s = 0; s < (MAXK / 2); s++)
                         {
                         if ((unsigned int)(2 * s * 64) < Tp)
                             {
@@ -755,12 +780,16 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                             nl_v2f r = dx * dx;
                             r = __builtin_elementwise_fma(dy, dy, r);
                             r = __builtin_elementwise_fma(dz, dz, r);
-                            const unsigned int t0 = __float_as_uint(r.x) - lo1;
+                            unsigned int t0 = __float_as_uint(r.x) - lo1;
+                            if (TWO)
+                                t0 -= (unsigned int)__builtin_amdgcn_sbfe((int)ctbits, 2 * s, 1) & lo1_d;
                             bits = __builtin_amdgcn_alignbit(bits, t0, 31);
                             nearest = min(nearest, t0);
                             if ((unsigned int)((2 * s + 1) * 64) < Tp)
                                 {
-                                const unsigned int t1 = __float_as_uint(r.y) - lo1;
+                                unsigned int t1 = __float_as_uint(r.y) - lo1;
+                                if (TWO)
+                                    t1 -= (unsigned int)__builtin_amdgcn_sbfe((int)ctbits, 2 * s + 1, 1) & lo1_d;
                                 bits = __builtin_amdgcn_alignbit(bits, t1, 31);
                                 nearest = min(nearest, t1);
                                 }
@@ -787,13 +816,13 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                             const double dy64 = HMD_SUB(HMD_SUB(piy, v.y), s_shift[3 * lo + 1]);
                             const double dz64 = HMD_SUB(HMD_SUB(piz, v.z), s_shift[3 * lo + 2]);
                             const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx64, dx64), HMD_MUL(dy64, dy64)), HMD_MUL(dz64, dz64));
-                            hit = rsq <= rl2;
+                            hit = rsq <= ((TWO && ((ctbits >> c) & 1u)) ? rl2_b : rl2);
                             }
                         bits = (bits << 1) | (hit ? 1u : 0u);
                         }
                     }
                 // the particle itself, by its place in the candidate list
-                const unsigned int k_self = self_first + hbase + iu - pbase; // (wraps below pbase: then >= NL_MAXK * 64)
+                const unsigned int k_self = self_first + hbase + iu - pbase; // (wraps below pbase: then >= MAXK * 64)
                 if ((k_self >> 6) < nslab && lane == (k_self & 63u))
                     bits &= ~(1u << (nslab - 1u - (k_self >> 6)));
                 // excluded partners, by particle index
@@ -804,7 +833,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         {
                         const unsigned int e = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
 #pragma unroll
-                        for (int c = 0; c < NL_MAXK; c++)
+                        for (int c = 0; c < MAXK; c++)
                             if ((unsigned int)(c * 64) < Tp && (TILE ? cidx[c] : co[c]) == e)
                                 bits &= ~(1u << (nslab - 1u - (unsigned int)c));
                         }
@@ -826,7 +855,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     unsigned int b = bits << (32u - nslab);
                     unsigned int pos = base - 1u;
 #pragma unroll
-                    for (int c = 0; c < NL_MAXK; c++)
+                    for (int c = 0; c < MAXK; c++)
                         {
                         if ((unsigned int)(c * 64) < Tp)
                             {
@@ -841,7 +870,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 else
                     {
 #pragma unroll
-                    for (int c = 0; c < NL_MAXK; c++)
+                    for (int c = 0; c < MAXK; c++)
                         {
                         if ((unsigned int)(c * 64) < Tp)
                             {
@@ -946,7 +975,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             if (a.d_last_updated_pos)
                 hmd_st4(a.d_last_updated_pos + hidx, hx, hy, hz, hmd_uint_as_double(hmd_double_as_uint(wtype)));
             if (cnt >= hnmax)
-                atomicMax(&a.d_conditions[0], cnt);
+                atomicMax(&a.d_conditions[htype], cnt);
             }
         }
     }
@@ -1201,26 +1230,54 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     for (int d = 0; d < 3; d++)
         if (a.box.periodic[d] && dim[d] < 3)
             fixed_images = false;
-    // one type, no body filter, fixed images, orthorhombic: the build with the fp32 pre-test
-    if (ST && !FB && fixed_images && hmd_box_is_ortho(a.box) && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY"))
+    // one or two types, no body filter, fixed images, orthorhombic: the build with the fp32 pre-test
+    if ((ST || a.ntypes == 2) && !FB && fixed_images && hmd_box_is_ortho(a.box) && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY"))
         {
         double wmax = 0.0;
         const double gw[3] = {a.ghost_width.x, a.ghost_width.y, a.ghost_width.z};
         for (int d = 0; d < 3; d++)
             wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
         const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF) + sizeof(double) * 3 * 64) * NL_WAVES;
+// candidates in registers: 12 slabs of 64 cover the 27 cells of liquids up to 28 particles per cell in one pass; denser
+// systems (the binary mixture at density 1.2) get 14 slabs rather than a second pass over a handful of candidates
+#define HMD_PREF_LAUNCH(TILE_, EXCL_, TWO_, ...)                                                                                                   \
+    do                                                                                                                                             \
+        {                                                                                                                                          \
+        if (27u * a.cli.w > 12u * 64u)                                                                                                             \
+            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 14>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
+        else                                                                                                                                       \
+            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 12>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
+        } while (0)
+        const bool two = !ST;
         if (d_tile && ex.d_n_ex)
-            hipLaunchKernelGGL((nlist_pref_kernel<true, true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
-                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+            {
+            if (two)
+                HMD_PREF_LAUNCH(true, true, true, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+            else
+                HMD_PREF_LAUNCH(true, true, false, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+            }
         else if (d_tile)
-            hipLaunchKernelGGL((nlist_pref_kernel<true, false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, d_tile, tile_capacity, d_tile_overflow,
-                               d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, no_ex);
+            {
+            if (two)
+                HMD_PREF_LAUNCH(true, false, true, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, no_ex);
+            else
+                HMD_PREF_LAUNCH(true, false, false, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, no_ex);
+            }
         else if (ex.d_n_ex)
-            hipLaunchKernelGGL((nlist_pref_kernel<false, true>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, 0u, ex);
+            {
+            if (two)
+                HMD_PREF_LAUNCH(false, true, true, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
+            else
+                HMD_PREF_LAUNCH(false, true, false, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
+            }
         else
-            hipLaunchKernelGGL((nlist_pref_kernel<false, false>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, nullptr, 0u, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, 0u, no_ex);
+            {
+            if (two)
+                HMD_PREF_LAUNCH(false, false, true, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, no_ex);
+            else
+                HMD_PREF_LAUNCH(false, false, false, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, no_ex);
+            }
+#undef HMD_PREF_LAUNCH
         return hmd_launch_status();
         }
     if (d_tile)

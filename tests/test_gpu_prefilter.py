@@ -29,9 +29,11 @@ def A():
     return _abi
 
 
-def _system(seed, L, n_free, n_pairs, r_list):
+def _system(seed, L, n_free, n_pairs, r_list, typ=None):
     """Random particles plus partners placed at r_list * (1 + eps) from some of them, eps from 0 and single ulps up
-    to 1e-5, in random directions, wrapped into the box (so some pairs straddle the periodic boundary)."""
+    to 1e-5, in random directions, wrapped into the box (so some pairs straddle the periodic boundary).  With types
+    (typ: type ids of the free particles followed by the partners'), r_list is the matrix and every engineered pair
+    sits at the r_list of its own type pair."""
     rng = np.random.default_rng(seed)
     Lb = np.asarray(L, dtype=np.float64)
     free = (rng.random((n_free, 3)) - 0.5) * Lb
@@ -45,6 +47,8 @@ def _system(seed, L, n_free, n_pairs, r_list):
     axis_dir = np.zeros((n_pairs, 3))
     axis_dir[np.arange(n_pairs), ax] = rng.choice([-1.0, 1.0], n_pairs)
     d = np.where((np.arange(n_pairs) % 3 == 0)[:, None], axis_dir, d)
+    if typ is not None:
+        r_list = np.asarray(r_list)[typ[src], typ[n_free:]]
     dist = r_list * (1.0 + eps[rng.integers(0, len(eps), n_pairs)])
     partners = free[src] + d * dist[:, None]
     xyz = np.concatenate([free, partners])
@@ -132,3 +136,35 @@ def test_prefilter_handles_coincident_particles_and_disabled_pairs(K, A):
             assert 1 in got[0] and 700 in got[0] and 0 in got[1] and 0 not in got[0]
         else:
             assert all(len(s) == 0 for s in got)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_prefiltered_build_with_two_types(K, A, seed):
+    """Two particle types: every type pair has its own r_list (and its own undecided band); engineered pairs sit at
+    the r_list of their own pair, one pair of types is switched off in the second case."""
+    L = (20.0, 17.0, 23.0)
+    r_buff = 0.4
+    r_cut = np.array([[2.5, 2.0], [2.0, 2.2]]) if seed == 3 else np.array([[2.5, 1.9], [1.9, -1.0]])
+    r_list = np.where(r_cut > 0, r_cut + r_buff, 1.7)  # (pairs of the switched-off kind are placed somewhere inside the cell width)
+    n_free, n_pairs = int(0.6 * L[0] * L[1] * L[2]), 4000
+    rng = np.random.default_rng(100 + seed)
+    typ = rng.integers(0, 2, n_free + n_pairs)
+    xyz = _system(seed, L, n_free, n_pairs, r_list, typ)
+    N = len(xyz)
+    pos = orc.pack_pos(xyz, typ)
+    obox, gbox = orc.Box.from_L(*L), A.Box.from_L(*L)
+    dim = orc.cell_dimensions(obox, 2.9)
+    ref = orc.nlist_binned(pos, N, obox, r_cut, r_buff, storage_full=True)
+    ref_sets = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    pos_t = torch.from_numpy(pos).cuda()
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+    rows = K.nlist_binned(pos_t, N, gbox, r_cut, r_buff, cl, adj)
+    tl = K.nlist_tiles(pos_t, N, gbox, r_cut, r_buff, cl, adj)
+    tl["nlist"] = K.tiles_to_rows(tl, N, gbox)
+    for nl in (rows, tl):
+        assert np.array_equal(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"])
+        got = orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                                nl["head"].cpu().numpy().view(np.uint64)[:N])
+        assert same_sets(got, ref_sets)
+    assert np.array_equal(np.sort(tl["Nmax"].cpu().numpy().view(np.uint32)), np.sort(ref["Nmax"]))
