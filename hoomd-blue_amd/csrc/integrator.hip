@@ -91,28 +91,36 @@ __global__ void publish_only_kernel(const unsigned int* d_result, unsigned long 
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
-template<bool CHECK, bool ORTHO> __global__ void __launch_bounds__(256) fused_step_kernel(hmd_fused_step_args_t a)
+// STEP_TWO false: the pass starts at the first half step (accelerations read from one.d_accel), for integration
+// methods whose two half steps cannot be joined (a thermostat needs the kinetic energy in between).
+template<bool CHECK, bool ORTHO, bool STEP_TWO = true> __global__ void __launch_bounds__(256) fused_step_kernel(hmd_fused_step_args_t a)
     {
     const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false;
     if (g < a.one.group_size)
         {
         const unsigned int idx = a.one.d_group_members ? a.one.d_group_members[g] : g;
-        const double4 f = hmd_ld4(a.two.d_net_force + idx);
         const double4 v = hmd_ld4(a.one.d_vel + idx);
         const double4 p = hmd_ld4(a.one.d_pos + idx);
-        // ---- step two (t) ----
-        const double minv = 1.0 / v.w;
         hmd_scalar3 acc;
-        acc.x = HMD_MUL(f.x, minv);
-        acc.y = HMD_MUL(f.y, minv);
-        acc.z = HMD_MUL(f.z, minv);
-        const double hdt = HMD_MUL(0.5, a.two.deltaT);
-        double vx = HMD_ADD(HMD_MUL(v.x, a.two.rescale_factor), HMD_MUL(hdt, acc.x));
-        double vy = HMD_ADD(HMD_MUL(v.y, a.two.rescale_factor), HMD_MUL(hdt, acc.y));
-        double vz = HMD_ADD(HMD_MUL(v.z, a.two.rescale_factor), HMD_MUL(hdt, acc.z));
-        if (a.two.d_accel)
-            a.two.d_accel[idx] = acc;
+        double vx = v.x, vy = v.y, vz = v.z;
+        if (STEP_TWO)
+            {
+            // ---- step two (t) ----
+            const double4 f = hmd_ld4(a.two.d_net_force + idx);
+            const double minv = 1.0 / v.w;
+            acc.x = HMD_MUL(f.x, minv);
+            acc.y = HMD_MUL(f.y, minv);
+            acc.z = HMD_MUL(f.z, minv);
+            const double hdt = HMD_MUL(0.5, a.two.deltaT);
+            vx = HMD_ADD(HMD_MUL(v.x, a.two.rescale_factor), HMD_MUL(hdt, acc.x));
+            vy = HMD_ADD(HMD_MUL(v.y, a.two.rescale_factor), HMD_MUL(hdt, acc.y));
+            vz = HMD_ADD(HMD_MUL(v.z, a.two.rescale_factor), HMD_MUL(hdt, acc.z));
+            if (a.two.d_accel)
+                a.two.d_accel[idx] = acc;
+            }
+        else
+            acc = a.one.d_accel[idx];
         // ---- step one (t+1) ----
         vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), a.one.rescale_factor);
         vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), a.one.rescale_factor);
@@ -349,6 +357,38 @@ extern "C" int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, voi
     // a separate one-wave kernel hands the flag to the host: making every workgroup's atomic visible to a
     // "last workgroup" inside the big kernel would need a device-wide fence per workgroup, which costs
     // far more across the eight XCDs than this launch
+    if (check && a.check.d_published)
+        hipLaunchKernelGGL(publish_only_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a.check.d_result, a.check.d_published, a.check.stamp);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_nvt_rescale_step_one_check(const hmd_fused_step_args_t* args, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_nvt_rescale_step_one_check: args is NULL");
+    const hmd_fused_step_args_t& a = *args;
+    HMD_REQUIRE(a.one.d_pos && a.one.d_vel && a.one.d_accel && a.one.d_image, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nvt_rescale_step_one_check: pos, vel, accel and image are required");
+    HMD_REQUIRE((a.d_cpos == nullptr) == (a.d_slot_of == nullptr), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nvt_rescale_step_one_check: d_cpos and d_slot_of go together");
+    HMD_REQUIRE(!a.one.use_limit, HMD_ERR_UNSUPPORTED, "hmd_nvt_rescale_step_one_check: the displacement limit needs the separate step-one driver");
+    const bool check = a.check.d_result != nullptr;
+    if (check)
+        {
+        HMD_REQUIRE(a.check.d_last_pos && a.check.d_rcut_max, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nvt_rescale_step_one_check: the check needs last_pos and rcut_max");
+        HMD_REQUIRE(a.one.d_group_members == nullptr && a.one.group_size == a.check.N, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nvt_rescale_step_one_check: the check needs the group of all particles");
+        }
+    if (a.one.group_size != 0)
+        {
+        const dim3 grid(hmd_div_up(a.one.group_size, 256));
+        if (!check)
+            hipLaunchKernelGGL((fused_step_kernel<false, true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (hmd_box_is_ortho(a.check.box))
+            hipLaunchKernelGGL((fused_step_kernel<true, true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((fused_step_kernel<true, false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        }
     if (check && a.check.d_published)
         hipLaunchKernelGGL(publish_only_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a.check.d_result, a.check.d_published, a.check.stamp);
     return hmd_launch_status();

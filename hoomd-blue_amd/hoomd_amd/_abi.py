@@ -289,6 +289,7 @@ _SIGNATURES = {
     "hmd_make_ghost_exchange_plan": (C.c_int, [C.POINTER(GhostPlanArgs), vp]),
     "hmd_pack_ghost_positions": (C.c_int, [C.POINTER(PackPosArgs), vp]),
     "hmd_nve_step_two_one_check": (C.c_int, [C.POINTER(FusedStepArgs), vp]),
+    "hmd_nvt_rescale_step_one_check": (C.c_int, [C.POINTER(FusedStepArgs), vp]),
     "hmd_nlist_tiles_supported": (C.c_int, [C.POINTER(Index3D), C.POINTER(Box), u32, u32, C.POINTER(u32)]),
     "hmd_nlist_tiles_storage_entries": (C.c_size_t, [C.POINTER(Index3D), u32, u32]),
     "hmd_tile_slots": (C.c_int, [C.POINTER(TileGeom), vp, vp]),

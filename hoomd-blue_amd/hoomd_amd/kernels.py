@@ -371,8 +371,9 @@ def step_two(vel, accel, net_force, dt, rescale=1.0, group=None):
 
 
 def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, rescale_one=1.0, group=None, last_pos=None, rcut_max=None,
-               r_buff=0.0, checkn=1, publish=False):
-    """hmd_nve_step_two_one_check; returns (flag word, published 64-bit word) when the check is requested."""
+               r_buff=0.0, checkn=1, publish=False, step_two=True, slot_of=None, cpos=None):
+    """hmd_nve_step_two_one_check (step_two=False: hmd_nvt_rescale_step_one_check, the first half step alone); returns
+    (flag word, published 64-bit word) when the check is requested."""
     dev = pos.device
     a = _abi.FusedStepArgs()
     n = pos.shape[0] if group is None else group.numel()
@@ -390,7 +391,12 @@ def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, resc
         if publish:
             pub = torch.zeros(1, dtype=torch.int64, device=dev)
             c.d_published, c.stamp = ptr(pub), checkn
-    check(_abi.lib.hmd_nve_step_two_one_check(C.byref(a), _stream(pos)), "hmd_nve_step_two_one_check")
+    if slot_of is not None:
+        a.d_slot_of, a.d_cpos = ptr(slot_of), ptr(cpos)
+    if step_two:
+        check(_abi.lib.hmd_nve_step_two_one_check(C.byref(a), _stream(pos)), "hmd_nve_step_two_one_check")
+    else:
+        check(_abi.lib.hmd_nvt_rescale_step_one_check(C.byref(a), _stream(pos)), "hmd_nvt_rescale_step_one_check")
     if res is None:
         return None
     return int(res.item()), (int(pub.item()) if pub is not None else None)

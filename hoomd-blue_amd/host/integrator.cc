@@ -42,6 +42,25 @@ void TwoStepConstantVolumeGPU::integrateStepOne(uint64_t timestep)
     a.deltaT = m_deltaT;
     a.use_limit = m_limit >= 0;
     a.maximum_displacement = m_limit;
+    // The neighbor list's distance check of the new positions and the slot-ordered position copy of the tile path ride
+    // in the same pass when the neighbor list takes the offer (the positions this half step produces are those of
+    // time step timestep + 1).
+    const auto& hook = m_pdata->getDisplacementCheckHook();
+    bool fused = false;
+    if (hook && !a.use_limit && a.d_group_members == nullptr && a.group_size == m_pdata->getN())
+        {
+        hmd_fused_step_args_t f;
+        std::memset(&f, 0, sizeof(f));
+        f.one = a;
+        hook(f, timestep + 1);
+        if (f.check.d_result || f.d_cpos)
+            {
+            ScopedKernelTimer t("step_one_check");
+            abiCheck(hmd_nvt_rescale_step_one_check(&f, nullptr), "hmd_nvt_rescale_step_one_check");
+            fused = true;
+            }
+        }
+    if (!fused)
         {
         ScopedKernelTimer t("step_one");
         abiCheck(hmd_nvt_rescale_step_one(&a, nullptr), "hmd_nvt_rescale_step_one");

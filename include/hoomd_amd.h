@@ -499,6 +499,12 @@ typedef struct
     hmd_scalar4* d_cpos;
     } hmd_fused_step_args_t;
 int hmd_nve_step_two_one_check(const hmd_fused_step_args_t* args, void* stream);
+/* The first half step alone with the same riders, for integration methods whose half steps cannot be joined (a
+   thermostat needs the kinetic energy of the finished step before it can scale the next one): gpu_nvt_rescale_step_one
+   (hoomd/md/TwoStepConstantVolumeGPU.cu:102-155) + gpu_nlist_needs_update_check_new (hoomd/md/NeighborListGPU.cu:86-97)
+   + the slot-ordered position copy, bit-identical to calling them in that order.  `two` is ignored; one.d_accel is
+   read; check / d_cpos / d_slot_of as above. */
+int hmd_nvt_rescale_step_one_check(const hmd_fused_step_args_t* args, void* stream);
 
 /* a = F/m for all N particles: Integrator::computeAccelerations (hoomd/Integrator.cc:106-127),
    which the reference runs on the host; here it stays on the device. */

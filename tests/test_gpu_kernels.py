@@ -519,6 +519,37 @@ def test_fused_half_steps_and_check_match_the_separate_drivers(K, A):
     assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v) and np.array_equal(ta.cpu().numpy(), a_)
 
 
+def test_first_half_step_with_check_and_slot_copy_matches_the_separate_drivers(K, A):
+    """hmd_nvt_rescale_step_one_check: step one with a thermostat's rescaling factor + distance check + slot-ordered
+    position copy in one kernel, bit-identical to the drivers run one after the other."""
+    xyz, typ, L = liquid(10, seed=16, ntypes=2)
+    N = len(xyz)
+    rng = np.random.default_rng(5)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    pos[:8, 0] = L / 2 - 1e-4
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    vel[:8, 0] = 1.0
+    accel = rng.normal(0, 5.0, (N, 3))
+    image = rng.integers(-2, 3, (N, 3)).astype(np.int32)
+    nf = np.zeros((N, 4))
+    last = pos.copy()
+    rcut_max = [2.5, 2.0]
+    slot_of = rng.permutation(2 * N)[:N].astype(np.int32)
+    for dt, scale, expect_move in ((0.005, 0.97, False), (0.08, 1.04, True)):
+        p, v, a_, im = pos.copy(), vel.copy(), accel.copy(), image.copy()
+        orc.step_one(p, v, a_, im, obox, dt, scale, None)
+        tp, tv, ta, ti, tnf, tl = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image, nf, last))
+        cpos = torch.zeros((2 * N, 4), dtype=torch.float64, device="cuda")
+        flag, pub = K.fused_step(tp, tv, ta, ti, tnf, gbox, dt, rescale_one=scale, last_pos=tl, rcut_max=rcut_max, r_buff=0.4, checkn=9, publish=True,
+                                 step_two=False, slot_of=torch.from_numpy(slot_of).cuda(), cpos=cpos)
+        assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v)
+        assert np.array_equal(ta.cpu().numpy(), accel) and np.array_equal(ti.cpu().numpy(), im)
+        want = K.nlist_check(torch.from_numpy(p).cuda(), tl, N, gbox, rcut_max, 0.4, checkn=9)
+        assert flag == want and (flag == 9) == expect_move and pub == (9 << 32) | flag
+        assert np.array_equal(cpos.cpu().numpy()[slot_of], p)
+
+
 def test_sum_net_force_and_thermo(K, A):
     rng = np.random.default_rng(4)
     N = 5000
