@@ -980,6 +980,412 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         }
     }
 
+// ---- the build for sparsely filled cells: one wave per block of 2x2x2 cells ----
+//
+// With a short cutoff a cell holds a handful of particles (3.3 in the bead-spring melt, r_list = 1.52), and a wave per
+// cell spends most of its instructions on set-up that serves three home particles.  Here a wave takes a whole block of
+// eight cells: the candidates are the members of the 4x4x4 cells around it (the tile path's region, about 210
+// particles: four slabs of 64 in registers), every home particle of the block tests all of them with the same fp32
+// pre-test and exact re-test as above, and a per-lane mask removes the candidates of region cells that are not
+// adjacent to the home particle's own cell, so that the pairs considered are exactly those of the 27-cell walk of
+// hoomd/md/NeighborListBinned.cc:85-176.  2.4 times the distance tests, a tenth of the set-up.  One type, orthorhombic box,
+// at least three cells along every periodic direction, at most MAXK members per cell (so one pass holds the region).
+template<bool TILE, bool EXCL, int MAXK>
+__global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_args_t a, unsigned int nblocks, double wmax, unsigned short* d_tile,
+                                                               unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
+                                                               unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group,
+                                                               unsigned int row_pieces, nl_excl_t ex)
+    {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    // per wave: 64 exclusive offsets, 64 region cells, 64 image shifts, 8 x 64 adjacency words, the row buffer
+    constexpr unsigned int PER_WAVE = 64 + 64 + 6 * 64 + 8 * 64 + NL_ROWBUF;
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int* s_excl = reinterpret_cast<unsigned int*>(s_raw) + PER_WAVE * wave;
+    unsigned int* s_cell = s_excl + 64;
+    double* s_shift = reinterpret_cast<double*>(s_cell + 64);
+    unsigned int* s_adj = s_cell + 64 + 6 * 64;
+    unsigned int* wrow = s_adj + 8 * 64;
+
+    const double rc0 = a.d_r_cut[0];
+    const double rl0 = HMD_ADD(rc0, a.r_buff);
+    const double rl2 = (rc0 > 0.0) ? HMD_MUL(rl0, rl0) : -1.0;
+    const nl_pref_t pf = nl_pref_thresholds(rl0, rl2, wmax);
+    const unsigned int lo1 = pf.hi > 0.0f ? __float_as_uint(pf.lo) + 1u : 0u;
+    const unsigned int band = pf.hi > 0.0f ? __float_as_uint(pf.hi) - __float_as_uint(pf.lo) : 0u;
+
+    const unsigned int tb = xcd_remap(blockIdx.x, gridDim.x) * NL_WAVES + wave;
+    if (tb >= nblocks)
+        return;
+    const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
+    const unsigned int nbx = (a.ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (a.ci.h + hmd::TB_Y - 1) / hmd::TB_Y;
+    const int c0[3] = {hmd::TB_X * (int)(tb % nbx), hmd::TB_Y * (int)((tb / nbx) % nby), hmd::TB_Z * (int)(tb / (nbx * nby))};
+
+    // ---- the region: cells, sizes -> exclusive offsets, image shifts ----
+    int rimg[3];
+    const int rcell = (int)lane < hmd::TL_RC ? hmd::tile_region_cell(a.ci, a.box, c0[0], c0[1], c0[2], (int)lane, rimg) : -1;
+    const unsigned int rsize = rcell >= 0 ? min(a.d_cell_size[rcell], a.cli.w) : 0u;
+    const unsigned int rincl = hmd::tile_wave_scan(rsize, (int)lane);
+    const unsigned int T = rl_u(rincl, 63);
+    s_excl[lane] = rincl - rsize;
+    s_cell[lane] = (unsigned int)rcell;
+    s_shift[3 * lane + 0] = rcell >= 0 ? (double)rimg[0] * a.box.L[0] : 0.0;
+    s_shift[3 * lane + 1] = rcell >= 0 ? (double)rimg[1] * a.box.L[1] : 0.0;
+    s_shift[3 * lane + 2] = rcell >= 0 ? (double)rimg[2] * a.box.L[2] : 0.0;
+
+    // home cells of the block (those inside the grid): sizes and their running sum
+    unsigned int hcum[hmd::TL_NH + 1];
+    hcum[0] = 0;
+#pragma unroll
+    for (int q = 0; q < hmd::TL_NH; q++)
+        {
+        const int qx = q % hmd::TB_X, qy = (q / hmd::TB_X) % hmd::TB_Y, qz = q / (hmd::TB_X * hmd::TB_Y);
+        const bool home = c0[0] + qx < dim[0] && c0[1] + qy < dim[1] && c0[2] + qz < dim[2];
+        hcum[q + 1] = hcum[q] + (home ? rl_u(rsize, (unsigned int)hmd::tile_home_rc(q)) : 0u);
+        }
+    const unsigned int H = hcum[hmd::TL_NH];
+
+    unsigned int tile_pad = 0, tile_grp0 = 0;
+    const unsigned int tile_row_cap = row_pieces * hmd::TL_PIECE;
+    if (TILE)
+        {
+        if (T > tile_capacity || __builtin_amdgcn_readfirstlane(d_tile_overflow[0]) != 0u)
+            {
+            if (lane == 0)
+                d_tile_overflow[0] = 1u;
+            return;
+            }
+        if (lane == 0 && T > d_tile_overflow[1])
+            atomicMax(d_tile_overflow + 1, T);
+        tile_pad = hmd::tile_slot(T);
+        tile_grp0 = __builtin_amdgcn_readfirstlane(d_block_group[tb]);
+        }
+    if (H == 0)
+        return;
+    if (T > (unsigned int)(MAXK * 64))
+        __builtin_trap(); // the launcher admits at most MAXK members per cell
+
+    // candidate k of the region: its region cell (largest entry of the offsets that does not exceed k)
+    auto cand_cell = [&](unsigned int k) -> unsigned int
+    {
+        unsigned int lo = 0;
+#pragma unroll
+        for (unsigned int step = 32; step > 0; step >>= 1)
+            if (s_excl[lo + step] <= k) // (lo + step <= 63)
+                lo += step;
+        return lo;
+    };
+    const unsigned int nslab = (T + 63u) / 64u;
+
+    // ---- candidates into registers: fp32 coordinates relative to the block's first home particle, what a row stores
+    // for them, and for every home cell q one word per lane with a bit per slab: is this candidate's cell adjacent to q ----
+    nl_v2f fx[MAXK / 2], fy[MAXK / 2], fz[MAXK / 2];
+    unsigned int co[MAXK];
+    unsigned int cidx[(EXCL && TILE) ? MAXK : 1];
+    unsigned int adjw[hmd::TL_NH];
+#pragma unroll
+    for (int q = 0; q < hmd::TL_NH; q++)
+        adjw[q] = 0;
+    // origin of the fp32 coordinates: the first candidate of the region (any fixed point near the block serves)
+    double Ox = 0, Oy = 0, Oz = 0;
+    constexpr int BATCH = MAXK / 2;
+#pragma unroll
+    for (int b0 = 0; b0 < MAXK; b0 += BATCH)
+        {
+        unsigned int w_[BATCH], lo_[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++)
+            {
+            const unsigned int k = (b0 + q) * 64 + lane;
+            lo_[q] = 0;
+            w_[q] = 0xffffffffu;
+            if ((unsigned int)((b0 + q) * 64) < T && k < T)
+                {
+                lo_[q] = cand_cell(k);
+                w_[q] = hmd_idx2(a.cli, k - s_excl[lo_[q]], s_cell[lo_[q]]);
+                }
+            }
+        double2 vxy[BATCH], vzw[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++)
+            {
+            const double2* src = reinterpret_cast<const double2*>(a.d_cell_xyzf + (w_[q] == 0xffffffffu ? 0u : w_[q]));
+            vxy[q] = src[0];
+            vzw[q] = src[1];
+            }
+        if (b0 == 0)
+            {
+            Ox = rl_d(HMD_ADD(vxy[0].x, s_shift[3 * lo_[0] + 0]), 0);
+            Oy = rl_d(HMD_ADD(vxy[0].y, s_shift[3 * lo_[0] + 1]), 0);
+            Oz = rl_d(HMD_ADD(vzw[0].x, s_shift[3 * lo_[0] + 2]), 0);
+            }
+#pragma unroll
+        for (int q = 0; q < BATCH; q++)
+            {
+            const int c = b0 + q;
+            float x32 = 1.0e18f, y32 = x32, z32 = x32;
+            co[c] = 0xffffffffu;
+            if (EXCL && TILE)
+                cidx[c] = 0xffffffffu;
+            if (w_[q] != 0xffffffffu)
+                {
+                const unsigned int lo = lo_[q];
+                x32 = (float)(HMD_ADD(vxy[q].x, s_shift[3 * lo + 0]) - Ox);
+                y32 = (float)(HMD_ADD(vxy[q].y, s_shift[3 * lo + 1]) - Oy);
+                z32 = (float)(HMD_ADD(vzw[q].x, s_shift[3 * lo + 2]) - Oz);
+                const unsigned int k = c * 64 + lane;
+                co[c] = TILE ? hmd::tile_slot(k) : hmd_double_as_uint(vzw[q].y);
+                if (EXCL && TILE)
+                    cidx[c] = hmd_double_as_uint(vzw[q].y);
+                // adjacency of the candidate's region cell (coordinates 0..3 per axis) to the home cells (1..2 per axis)
+                const unsigned int rx = lo % hmd::TR_X, ry = (lo / hmd::TR_X) % hmd::TR_Y, rz = lo / (hmd::TR_X * hmd::TR_Y);
+#pragma unroll
+                for (int hq = 0; hq < hmd::TL_NH; hq++)
+                    {
+                    const int hx = hq % hmd::TB_X + 1, hy = (hq / hmd::TB_X) % hmd::TB_Y + 1, hz = hq / (hmd::TB_X * hmd::TB_Y) + 1;
+                    const bool adj = (int)rx >= hx - 1 && (int)rx <= hx + 1 && (int)ry >= hy - 1 && (int)ry <= hy + 1 && (int)rz >= hz - 1 && (int)rz <= hz + 1;
+                    if (adj)
+                        adjw[hq] |= 1u << (nslab - 1u - (unsigned int)c); // slab c at bit nslab - 1 - c, like the hit words
+                    }
+                }
+            if (c & 1)
+                {
+                fx[c / 2].y = x32;
+                fy[c / 2].y = y32;
+                fz[c / 2].y = z32;
+                }
+            else
+                {
+                fx[c / 2].x = x32;
+                fy[c / 2].x = y32;
+                fz[c / 2].x = z32;
+                }
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < hmd::TL_NH; q++)
+        s_adj[q * 64 + lane] = adjw[q];
+
+    // ---- the home particles of the block, 64 at a time ----
+    for (unsigned int hbase = 0; hbase < H; hbase += 64)
+        {
+        const unsigned int nh = min(H - hbase, 64u);
+        double hx = 0, hy = 0, hz = 0;
+        unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0, hq = 0, hself = 0, hslot = 0;
+        if (lane < nh)
+            {
+            const unsigned int hn = hbase + lane;
+#pragma unroll
+            for (int q = 1; q < hmd::TL_NH; q++)
+                hq += hn >= hcum[q] ? 1u : 0u;
+            unsigned int first = 0, rc = 0;
+#pragma unroll
+            for (int q = 0; q < hmd::TL_NH; q++)
+                if ((unsigned int)q == hq)
+                    {
+                    first = hcum[q];
+                    rc = (unsigned int)hmd::tile_home_rc(q);
+                    }
+            const unsigned int m = hn - first;
+            hslot = hmd_idx2(a.cli, m, s_cell[rc]);
+            hself = s_excl[rc] + m;
+            const double4 v = hmd_ld4(a.d_cell_xyzf + hslot);
+            hx = v.x;
+            hy = v.y;
+            hz = v.z;
+            hidx = hmd_double_as_uint(v.w);
+            if (hidx < a.N)
+                hnmax = a.d_Nmax[0];
+            }
+        const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
+
+        for (unsigned int i = 0; i < nh; i++)
+            {
+            const unsigned int iu = __builtin_amdgcn_readfirstlane(i);
+            const unsigned int i_idx = rl_u(hidx, iu);
+            if (i_idx >= a.N)
+                continue; // ghosts get no row
+            const float pxs = __uint_as_float(rl_u(__float_as_uint(hxf), iu)), pys = __uint_as_float(rl_u(__float_as_uint(hyf), iu)),
+                        pzs = __uint_as_float(rl_u(__float_as_uint(hzf), iu));
+            const nl_v2f px = {pxs, pxs}, py = {pys, pys}, pz = {pzs, pzs};
+            const unsigned int nmax_i = rl_u(hnmax, iu);
+            const unsigned int nmax_w = TILE ? min(nmax_i, tile_row_cap) : nmax_i;
+            const unsigned int q_i = rl_u(hq, iu);
+
+            unsigned int bits = 0, nearest = 0xffffffffu;
+            if (band != 0u)
+                {
+#pragma unroll
+                for (int s = 0; s < MAXK / 2; s++)
+                    {
+                    if ((unsigned int)(2 * s * 64) < T)
+                        {
+                        const nl_v2f dx = px - fx[s], dy = py - fy[s], dz = pz - fz[s];
+                        nl_v2f r = dx * dx;
+                        r = __builtin_elementwise_fma(dy, dy, r);
+                        r = __builtin_elementwise_fma(dz, dz, r);
+                        const unsigned int t0 = __float_as_uint(r.x) - lo1;
+                        bits = __builtin_amdgcn_alignbit(bits, t0, 31);
+                        nearest = min(nearest, t0);
+                        if ((unsigned int)((2 * s + 1) * 64) < T)
+                            {
+                            const unsigned int t1 = __float_as_uint(r.y) - lo1;
+                            bits = __builtin_amdgcn_alignbit(bits, t1, 31);
+                            nearest = min(nearest, t1);
+                            }
+                        }
+                    }
+                }
+            if (__ballot(nearest < band))
+                {
+                // a candidate sits in the band around r_list^2: every slab again with the CPU path's own arithmetic
+                const double pix = rl_d(hx, iu), piy = rl_d(hy, iu), piz = rl_d(hz, iu);
+                bits = 0;
+                for (unsigned int c = 0; c < nslab; c++)
+                    {
+                    const unsigned int k = c * 64 + lane;
+                    bool hit = false;
+                    if (k < T)
+                        {
+                        const unsigned int lo = cand_cell(k);
+                        const double4 v = hmd_ld4(a.d_cell_xyzf + hmd_idx2(a.cli, k - s_excl[lo], s_cell[lo]));
+                        const double dx64 = HMD_SUB(HMD_SUB(pix, v.x), s_shift[3 * lo + 0]);
+                        const double dy64 = HMD_SUB(HMD_SUB(piy, v.y), s_shift[3 * lo + 1]);
+                        const double dz64 = HMD_SUB(HMD_SUB(piz, v.z), s_shift[3 * lo + 2]);
+                        const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx64, dx64), HMD_MUL(dy64, dy64)), HMD_MUL(dz64, dz64));
+                        hit = rsq <= rl2;
+                        }
+                    bits = (bits << 1) | (hit ? 1u : 0u);
+                    }
+                }
+            // only candidates of the 27 cells around the particle's own cell; not the particle itself
+            bits &= s_adj[q_i * 64 + lane];
+            const unsigned int k_self = rl_u(hself, iu);
+            if (lane == (k_self & 63u))
+                bits &= ~(1u << (nslab - 1u - (k_self >> 6)));
+            if (EXCL)
+                {
+                const unsigned int nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
+                for (unsigned int o = 0; o < nex_i; o++)
+                    {
+                    const unsigned int e = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+#pragma unroll
+                    for (int c = 0; c < MAXK; c++)
+                        if ((unsigned int)(c * 64) < T && (TILE ? cidx[c] : co[c]) == e)
+                            bits &= ~(1u << (nslab - 1u - (unsigned int)c));
+                    }
+                }
+
+            // ---- compaction: hits ordered by lane, then slab ----
+            const unsigned int mine = (unsigned int)__popc(bits);
+            const unsigned int incl = nl_wave_scan_dpp(mine);
+            const unsigned int cnt_new = rl_u(incl, 63);
+            const unsigned int base = incl - mine;
+            const unsigned int h_i = hbase + iu;
+            unsigned short* trow16 = TILE ? d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE
+                                          : nullptr;
+            unsigned int* irow = TILE ? nullptr : a.d_nlist + a.d_head_list[i_idx];
+            const bool fits = cnt_new <= min(nmax_w, (unsigned int)NL_ROWBUF);
+            if (fits)
+                {
+                unsigned int b = bits << (32u - nslab);
+                unsigned int pos = base - 1u;
+#pragma unroll
+                for (int c = 0; c < MAXK; c++)
+                    {
+                    if ((unsigned int)(c * 64) < T)
+                        {
+                        const bool hit = (int)b < 0;
+                        b <<= 1;
+                        pos += hit ? 1u : 0u;
+                        if (hit)
+                            wrow[pos] = co[c];
+                        }
+                    }
+                if (TILE)
+                    {
+                    const unsigned int padded = (cnt_new + 3u) & ~3u;
+                    const unsigned int e = 2u * lane;
+                    if (e < padded)
+                        {
+                        const uint2 w2 = *reinterpret_cast<const uint2*>(wrow + e);
+                        const unsigned int v0 = e < cnt_new ? w2.x : tile_pad, v1 = e + 1u < cnt_new ? w2.y : tile_pad;
+                        *reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(trow16) + (((lane >> 3) << 9) | ((lane & 7u) << 2))) = (v0 & 0xffffu) | (v1 << 16);
+                        }
+                    }
+                else
+                    {
+#pragma unroll
+                    for (unsigned int e0 = 0; e0 < (unsigned int)NL_ROWBUF; e0 += 64)
+                        if (e0 + lane < cnt_new)
+                            irow[e0 + lane] = wrow[e0 + lane];
+                    }
+                }
+            else
+                {
+                // the row is longer than its capacity (the caller grows Nmax and builds again) or than the staging
+                // buffer: entries that have room go straight to memory
+#pragma unroll
+                for (int c = 0; c < MAXK; c++)
+                    {
+                    if ((unsigned int)(c * 64) < T)
+                        {
+                        const unsigned int bp = nslab - 1u - (unsigned int)c;
+                        const unsigned int pos = base + (unsigned int)__popc(bits >> 1 >> bp);
+                        if (((bits >> bp) & 1u) && pos < nmax_w)
+                            {
+                            if (TILE)
+                                trow16[((pos & ~15u) << 4) | (pos & 15u)] = (unsigned short)co[c];
+                            else
+                                irow[pos] = co[c];
+                            }
+                        }
+                    }
+                }
+            if (lane == iu)
+                cnt = cnt_new;
+            }
+
+        // ---- per-particle results ----
+        if (TILE && d_slot_meta && lane < nh && hidx >= a.N)
+            {
+            hmd_uint4 m = {hidx, 0u, 0u, 0u}; // a ghost: no row
+            d_slot_meta[hslot] = m;
+            if (d_slot_of)
+                {
+                d_slot_of[hidx] = hslot;
+                hmd_st4(d_cpos + hslot, hx, hy, hz, a.d_pos[hidx].w);
+                }
+            }
+        if (lane < nh && hidx < a.N)
+            {
+            const double wtype = a.d_pos[hidx].w;
+            if (TILE && d_slot_meta)
+                {
+                hmd_uint4 m = {hidx, cnt, 0u, 0u};
+                d_slot_meta[hslot] = m;
+                if (d_slot_of)
+                    {
+                    d_slot_of[hidx] = hslot;
+                    hmd_st4(d_cpos + hslot, hx, hy, hz, wtype);
+                    }
+                }
+            a.d_n_neigh[hidx] = cnt;
+            if (TILE)
+                {
+                const unsigned int h_i = hbase + lane;
+                unsigned short* trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
+                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < min(hnmax, tile_row_cap); k++)
+                    trow[((k & ~15u) << 4) | (k & 15u)] = (unsigned short)tile_pad;
+                }
+            if (a.d_last_updated_pos)
+                hmd_st4(a.d_last_updated_pos + hidx, hx, hy, hz, hmd_uint_as_double(hmd_double_as_uint(wtype)));
+            if (cnt >= hnmax)
+                atomicMax(&a.d_conditions[0], cnt);
+            }
+        }
+    }
+
 template<bool ORTHO>
 __global__ void __launch_bounds__(256) nlist_check_kernel(hmd_nlist_check_args_t a)
     {
@@ -1230,6 +1636,32 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     for (int d = 0; d < 3; d++)
         if (a.box.periodic[d] && dim[d] < 3)
             fixed_images = false;
+    // sparsely filled cells (at most 12 members in any cell; one type): a wave per block of eight cells
+    if (ST && !FB && fixed_images && hmd_box_is_ortho(a.box) && a.cli.w <= 12 && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY")
+        && !std::getenv("HOOMD_AMD_NLIST_NO_BLOCK_BUILD"))
+        {
+        double wmax = 0.0;
+        const double gw[3] = {a.ghost_width.x, a.ghost_width.y, a.ghost_width.z};
+        for (int d = 0; d < 3; d++)
+            wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
+        // (fp32 coordinates are relative to a point of the 4x4x4-cell region: up to four cell widths away, not two)
+        wmax *= 2.0;
+        const unsigned int nblk = hmd::tile_num_blocks(a.ci);
+        const dim3 bgrid(hmd_div_up(nblk, NL_WAVES));
+        const size_t lds_blk = sizeof(unsigned int) * (64 + 64 + 6 * 64 + 8 * 64 + NL_ROWBUF) * NL_WAVES;
+#define HMD_BLOCK_LAUNCH(TILE_, EXCL_, ...) \
+    hipLaunchKernelGGL((nlist_block_kernel<TILE_, EXCL_, 12>), bgrid, dim3(NL_BLOCK), lds_blk, s, a, nblk, wmax, __VA_ARGS__)
+        if (d_tile && ex.d_n_ex)
+            HMD_BLOCK_LAUNCH(true, true, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
+        else if (d_tile)
+            HMD_BLOCK_LAUNCH(true, false, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, no_ex);
+        else if (ex.d_n_ex)
+            HMD_BLOCK_LAUNCH(false, true, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, ex);
+        else
+            HMD_BLOCK_LAUNCH(false, false, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, no_ex);
+#undef HMD_BLOCK_LAUNCH
+        return hmd_launch_status();
+        }
     // one or two types, no body filter, fixed images, orthorhombic: the build with the fp32 pre-test
     if ((ST || a.ntypes == 2) && !FB && fixed_images && hmd_box_is_ortho(a.box) && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY"))
         {

@@ -168,3 +168,54 @@ def test_prefiltered_build_with_two_types(K, A, seed):
                                 nl["head"].cpu().numpy().view(np.uint64)[:N])
         assert same_sets(got, ref_sets)
     assert np.array_equal(np.sort(tl["Nmax"].cpu().numpy().view(np.uint32)), np.sort(ref["Nmax"]))
+
+
+@pytest.mark.parametrize("L,seed,excl", [((20.0, 17.0, 23.0), 7, False), ((9.5, 14.0, 6.2), 8, True), ((31.0, 5.0, 12.0), 9, True)])
+def test_block_build_for_sparse_cells(K, A, L, seed, excl):
+    """Short cutoff, about three particles per cell: the build that gives a wave a block of 2x2x2 cells and the 4x4x4
+    cells around it as candidates.  Same sets as the CPU path, pairs engineered onto r_list included, odd grids and a
+    grid of three cells along one axis (the region then holds two images of the same cell), with and without
+    exclusions, as index rows and as tile rows."""
+    r_cut, r_buff = 2.0 ** (1.0 / 6.0), 0.4
+    r_list = r_cut + r_buff
+    n_free = int(0.6 * L[0] * L[1] * L[2])
+    xyz = _system(seed, L, n_free, n_free // 4, r_list)
+    N = len(xyz)
+    pos = orc.pack_pos(xyz, np.zeros(N, dtype=int))
+    obox, gbox = orc.Box.from_L(*L), A.Box.from_L(*L)
+    dim = orc.cell_dimensions(obox, r_list)
+    assert min(dim) >= 3
+    ref = orc.nlist_binned(pos, N, obox, [[r_cut]], r_buff, storage_full=True)
+    n_neigh, nlist = ref["n_neigh"].copy(), ref["nlist"].copy()
+    ex_t = None
+    if excl:
+        n_ex = np.zeros(N, dtype=np.uint32)
+        ex = np.zeros((2, N), dtype=np.uint32)
+        for i in range(0, N - 1, 3):  # "bonds" between consecutive particles and between engineered partners
+            j = i + 1
+            ex[n_ex[i], i], ex[n_ex[j], j] = j, i
+            n_ex[i] += 1
+            n_ex[j] += 1
+        orc.nlist_filter(N, ref["head"], n_ex, ex, n_neigh, nlist)
+        ex_t = (torch.from_numpy(n_ex.view(np.int32)).cuda(), torch.from_numpy(ex.view(np.int32)).cuda())
+    want = orc.neighbor_sets(n_neigh, nlist, ref["head"])
+    pos_t = torch.from_numpy(pos).cuda()
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+    assert cl["Nmax"] <= 12  # the build under test is the one chosen
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+    rows = K.nlist_binned(pos_t, N, gbox, [[r_cut]], r_buff, cl, adj, exclusions=ex_t)
+    tl = K.nlist_tiles(pos_t, N, gbox, [[r_cut]], r_buff, cl, adj, exclusions=ex_t)
+    tl["nlist"] = K.tiles_to_rows(tl, N, gbox)
+    for nl in (rows, tl):
+        assert np.array_equal(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], n_neigh)
+        got = orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                                nl["head"].cpu().numpy().view(np.uint64)[:N])
+        assert same_sets(got, want)
+        assert np.array_equal(nl["last_pos"].cpu().numpy()[:N, :3], pos[:, :3])
+    # the same through the kernel that walks cell by cell
+    os.environ["HOOMD_AMD_NLIST_NO_BLOCK_BUILD"] = "1"
+    try:
+        rows2 = K.nlist_binned(pos_t, N, gbox, [[r_cut]], r_buff, cl, adj, exclusions=ex_t)
+    finally:
+        os.environ.pop("HOOMD_AMD_NLIST_NO_BLOCK_BUILD", None)
+    assert np.array_equal(rows2["n_neigh"].cpu().numpy(), rows["n_neigh"].cpu().numpy())
