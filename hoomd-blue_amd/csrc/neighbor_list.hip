@@ -1670,12 +1670,14 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
         for (int d = 0; d < 3; d++)
             wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
         const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF) + sizeof(double) * 3 * 64) * NL_WAVES;
-// candidates in registers: 12 slabs of 64 cover the 27 cells of liquids up to 28 particles per cell in one pass; denser
-// systems (the binary mixture at density 1.2) get 14 slabs rather than a second pass over a handful of candidates
+// candidates in registers: 12 slabs of 64 cover the 27 cells of liquids up to 28 particles per cell in one pass (the
+// LJ liquid has 21.5); denser systems (the binary mixture at density 1.2: 29) get 14 slabs, at three waves per SIMD
+// instead of four, rather than a second pass over a handful of candidates.  Decided by the mean occupancy.
+        const bool dense = 27.0 * (double)a.N / (double)ncells > 0.92 * 12.0 * 64.0;
 #define HMD_PREF_LAUNCH(TILE_, EXCL_, TWO_, ...)                                                                                                   \
     do                                                                                                                                             \
         {                                                                                                                                          \
-        if (27u * a.cli.w > 12u * 64u)                                                                                                             \
+        if (dense)                                                                                                                                 \
             hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 14>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
         else                                                                                                                                       \
             hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 12>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
