@@ -282,6 +282,75 @@ __global__ void __launch_bounds__(256) unpack_init_kernel(hmd_unpack_ghost_init_
     a.arrays.d_diameter[i] = 1.0;
     }
 
+__global__ void __launch_bounds__(64) migrate_headers_kernel(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, unsigned int* d_words)
+    {
+    const unsigned int r = threadIdx.x;
+    if (r >= n_ranks)
+        return;
+    const long long* h = d_in + (size_t)r * (slot_rows + 1) * HMD_MIGRATE_ROW_WORDS;
+    d_words[2 * r] = (unsigned int)h[0];
+    d_words[2 * r + 1] = (unsigned int)h[1];
+    }
+
+// rank whose range [off[r], off[r + 1]) holds k (k < off[n_ranks])
+__device__ __forceinline__ unsigned int slot_rank_of(const hmd_ghost_slots_t& s, unsigned int k)
+    {
+    unsigned int r = 0;
+    while (r + 1 < s.n_ranks && s.off[r + 1] <= k)
+        r++;
+    return r;
+    }
+
+__global__ void __launch_bounds__(256) pack_init_slots_kernel(hmd_pack_pos_args_t a, const unsigned int* d_tag, hmd_ghost_slots_t s)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < a.n_send)
+        {
+        const unsigned int r = slot_rank_of(s, k), local = k - s.off[r];
+        if (local < s.cap[r])
+            {
+            const unsigned int i = a.d_send_idx[k];
+            const double4 p = hmd_ld4(a.d_pos + i);
+            const hmd_scalar3 sh = a.d_shift_table[a.d_send_shift_id[k]];
+            const double w = __hiloint2double((int)d_tag[i], (int)hmd_double_as_uint(p.w));
+            hmd_st4(a.d_out + (size_t)s.row0[r] + 1 + local, HMD_ADD(p.x, sh.x), HMD_ADD(p.y, sh.y), HMD_ADD(p.z, sh.z), w);
+            }
+        }
+    else if (k < a.n_send + s.n_ranks)
+        {
+        const unsigned int r = k - a.n_send;
+        hmd_st4(a.d_out + s.row0[r], hmd_uint_as_double(s.off[r + 1] - s.off[r]), hmd_uint_as_double(s.flag), 0.0, 0.0);
+        }
+    }
+
+__global__ void __launch_bounds__(64) slot_headers_kernel(const hmd_scalar4* d_in, hmd_ghost_slots_t s, unsigned int* d_words)
+    {
+    const unsigned int r = threadIdx.x;
+    if (r >= s.n_ranks)
+        return;
+    const double4 p = hmd_ld4(d_in + s.row0[r]);
+    d_words[2 * r] = hmd_double_as_uint(p.x);
+    d_words[2 * r + 1] = hmd_double_as_uint(p.y);
+    }
+
+__global__ void __launch_bounds__(256) unpack_init_slots_kernel(hmd_unpack_ghost_init_args_t a, hmd_ghost_slots_t s)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n)
+        return;
+    const unsigned int r = slot_rank_of(s, k);
+    const double4 p = hmd_ld4(a.d_in + (size_t)s.row0[r] + 1 + (k - s.off[r]));
+    const unsigned int i = a.first + k;
+    hmd_st4(a.arrays.d_pos + i, p.x, p.y, p.z, hmd_uint_as_double(hmd_double_as_uint(p.w)));
+    a.arrays.d_tag[i] = (unsigned int)__double2hiint(p.w);
+    hmd_int3 zero;
+    zero.x = zero.y = zero.z = 0;
+    a.arrays.d_image[i] = zero;
+    a.arrays.d_body[i] = 0xffffffffu;
+    a.arrays.d_charge[i] = 0.0;
+    a.arrays.d_diameter[i] = 1.0;
+    }
+
 __global__ void __launch_bounds__(256) vote_plan_kernel(hmd_vote_plan_args_t a)
     {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,11 +656,71 @@ extern "C" int hmd_unpack_ghost_init(const hmd_unpack_ghost_init_args_t* args, v
     return hmd_launch_status();
     }
 
+extern "C" int hmd_migrate_slot_headers(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, unsigned int* d_words, void* stream)
+    {
+    HMD_REQUIRE(d_in && d_words && slot_rows >= 1 && n_ranks >= 1 && n_ranks <= 64, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_slot_headers: d_in, d_words, slot_rows >= 1 and 1 to 64 ranks are required");
+    hipLaunchKernelGGL(migrate_headers_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, slot_rows, n_ranks, d_words);
+    return hmd_launch_status();
+    }
+
+static int ghost_slots_check(const hmd_ghost_slots_t* s, const char* who)
+    {
+    HMD_REQUIRE(s && s->n_ranks >= 1 && s->n_ranks <= HMD_GHOST_SLOTS_MAX_RANKS, HMD_ERR_INVALID_ARGUMENT, who);
+    HMD_REQUIRE(s->off[0] == 0, HMD_ERR_INVALID_ARGUMENT, who);
+    for (unsigned int r = 0; r < s->n_ranks; r++)
+        {
+        HMD_REQUIRE(s->off[r] <= s->off[r + 1], HMD_ERR_INVALID_ARGUMENT, who);
+        // messages must not overlap in the buffer
+        HMD_REQUIRE(r + 1 == s->n_ranks || s->row0[r] + s->cap[r] + 1 <= s->row0[r + 1], HMD_ERR_INVALID_ARGUMENT, who);
+        }
+    return HMD_OK;
+    }
+
+extern "C" int hmd_pack_ghost_init_slots(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, const hmd_ghost_slots_t* slots, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots: args is NULL");
+    if (const int rc = ghost_slots_check(slots, "hmd_pack_ghost_init_slots: 1 to 64 ranks, offsets from 0 that do not decrease, messages that do not overlap"))
+        return rc;
+    HMD_REQUIRE(slots->off[slots->n_ranks] == args->n_send, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots: the offsets must end at n_send");
+    HMD_REQUIRE(args->d_out, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots: d_out is required");
+    HMD_REQUIRE(args->n_send == 0 || (args->d_pos && args->d_send_idx && args->d_send_shift_id && args->d_shift_table && d_tag), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_init_slots: all array arguments are required");
+    hipLaunchKernelGGL(pack_init_slots_kernel, dim3(hmd_div_up(args->n_send + slots->n_ranks, 256)), dim3(256), 0, (hipStream_t)stream, *args, d_tag, *slots);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_ghost_slot_headers(const hmd_scalar4* d_in, const hmd_ghost_slots_t* slots, unsigned int* d_words, void* stream)
+    {
+    HMD_REQUIRE(d_in && d_words && slots && slots->n_ranks >= 1 && slots->n_ranks <= HMD_GHOST_SLOTS_MAX_RANKS, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_ghost_slot_headers: d_in, d_words and 1 to 64 ranks are required");
+    hipLaunchKernelGGL(slot_headers_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, *slots, d_words);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_unpack_ghost_init_slots(const hmd_unpack_ghost_init_args_t* args, const hmd_ghost_slots_t* slots, void* stream)
+    {
+    HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_unpack_ghost_init_slots: args is NULL");
+    if (const int rc = ghost_slots_check(slots, "hmd_unpack_ghost_init_slots: 1 to 64 ranks, offsets from 0 that do not decrease, messages that do not overlap"))
+        return rc;
+    HMD_REQUIRE(slots->off[slots->n_ranks] == args->n, HMD_ERR_INVALID_ARGUMENT, "hmd_unpack_ghost_init_slots: the offsets must end at n");
+    for (unsigned int r = 0; r < slots->n_ranks; r++)
+        HMD_REQUIRE(slots->off[r + 1] - slots->off[r] <= slots->cap[r], HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_unpack_ghost_init_slots: a message cannot hold more rows than it has room for");
+    if (args->n == 0)
+        return HMD_OK;
+    const hmd_pdata_arrays_t& p = args->arrays;
+    HMD_REQUIRE(args->d_in && p.d_pos && p.d_image && p.d_tag && p.d_body && p.d_charge && p.d_diameter, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_unpack_ghost_init_slots: d_in and the pos, image, tag, body, charge and diameter arrays are required");
+    hipLaunchKernelGGL(unpack_init_slots_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args, *slots);
+    return hmd_launch_status();
+    }
+
 extern "C" int hmd_vote_plan(const hmd_vote_plan_args_t* args, void* stream)
     {
     HMD_REQUIRE(args, HMD_ERR_INVALID_ARGUMENT, "hmd_vote_plan: args is NULL");
-    HMD_REQUIRE(args->n_ranks >= 2 && args->n_ranks <= HMD_VOTE_PLAN_MAX_RANKS && args->rank < args->n_ranks, HMD_ERR_INVALID_ARGUMENT,
-                "hmd_vote_plan: between 2 and 64 ranks");
+    HMD_REQUIRE(args->n_ranks >= 1 && args->n_ranks <= HMD_VOTE_PLAN_MAX_RANKS && args->rank < args->n_ranks, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_vote_plan: between 1 and 64 ranks");
     for (unsigned int r = 0; r < args->n_ranks; r++)
         HMD_REQUIRE(args->send_off[r] <= args->send_off[r + 1] && args->recv_off[r] <= args->recv_off[r + 1], HMD_ERR_INVALID_ARGUMENT,
                     "hmd_vote_plan: offsets must not decrease");

@@ -189,6 +189,10 @@ class UnpackGhostInitArgs(C.Structure):
     _fields_ = [("d_in", vp), ("n", u32), ("first", u32), ("arrays", PDataArraysStruct)]
 
 
+class GhostSlots(C.Structure):
+    _fields_ = [("n_ranks", u32), ("flag", u32), ("off", u32 * 65), ("row0", u32 * 64), ("cap", u32 * 64)]
+
+
 VOTE_PLAN_MAX_RANKS = 64
 
 
@@ -264,6 +268,10 @@ _SIGNATURES = {
     "hmd_ghost_split_keys": (C.c_int, [vp, u32, vp, vp, vp]),
     "hmd_pack_ghost_init": (C.c_int, [C.POINTER(PackPosArgs), vp, vp]),
     "hmd_unpack_ghost_init": (C.c_int, [C.POINTER(UnpackGhostInitArgs), vp]),
+    "hmd_pack_ghost_init_slots": (C.c_int, [C.POINTER(PackPosArgs), vp, C.POINTER(GhostSlots), vp]),
+    "hmd_ghost_slot_headers": (C.c_int, [vp, C.POINTER(GhostSlots), vp, vp]),
+    "hmd_unpack_ghost_init_slots": (C.c_int, [C.POINTER(UnpackGhostInitArgs), C.POINTER(GhostSlots), vp]),
+    "hmd_migrate_slot_headers": (C.c_int, [vp, u32, u32, vp, vp]),
     "hmd_vote_plan": (C.c_int, [C.POINTER(VotePlanArgs), vp]),
     "hmd_migrate_pack": (C.c_int, [C.POINTER(MigratePackArgs), vp]),
     "hmd_migrate_fill": (C.c_int, [C.POINTER(MigrateFillArgs), vp]),

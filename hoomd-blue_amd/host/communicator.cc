@@ -115,7 +115,7 @@ CommunicatorGPU::CommunicatorGPU(std::shared_ptr<SystemDefinition> sysdef, std::
     for (unsigned int r = 0; r < world; r++)
         if (r != rank)
             others.push_back(r);
-    m_all_peers = world >= 2 && peers == others;
+    m_all_peers = peers == others; // (one rank: no peers, no other ranks)
     m_fixed_migrate = m_all_peers && world <= 64;
     m_send_rows.assign(world, 0);
     m_recv_rows.assign(world, 0);
@@ -123,7 +123,7 @@ CommunicatorGPU::CommunicatorGPU(std::shared_ptr<SystemDefinition> sysdef, std::
     m_mig_keys.resize(4096, false);
     m_send_counters.resize(1 + 26, false);
     m_count_out.resize(world, false);
-    m_count_in.resize(world, false);
+    m_count_in.resize(2 * (size_t)world, false);
     }
 
 unsigned int CommunicatorGPU::rankAt(int i, int j, int k) const
@@ -264,7 +264,8 @@ bool CommunicatorGPU::migrateParticles()
             }
         pk.send_off[m_world] = off;
         pk.n_ranks = m_world;
-        std::vector<long long> headers(2 * (size_t)m_world);
+        std::vector<unsigned int> headers(2 * (size_t)m_world);
+        ensure(m_count_in, 2 * (size_t)m_world, 1.0, 0);
         while (true)
             {
             slot_rows = m_mig_slot_rows;
@@ -279,19 +280,20 @@ bool CommunicatorGPU::migrateParticles()
             abiCheck(hmd_migrate_pack(&pk, nullptr), "hmd_migrate_pack");
             const std::vector<unsigned int> each(m_world, slot_rows + 1);
             m_transport->allToAll((uintptr_t)m_mig_out.get(), each, (uintptr_t)m_mig_in.get(), each, ROW_BYTES, 0);
-            // word 0 and 1 of the first row of every message (the copy waits for the default stream)
-            hipCheck(hipMemcpy2D(headers.data(), 16, m_mig_in.get(), (size_t)(slot_rows + 1) * ROW_BYTES, 16, m_world, hipMemcpyDeviceToHost),
-                     "migration headers D2H");
-            long long most = 0;
+            // word 0 and 1 of the first row of every message
+            abiCheck(hmd_migrate_slot_headers(m_mig_in.get(), slot_rows, m_world, m_count_in.get(), nullptr), "hmd_migrate_slot_headers");
+            for (unsigned int o = 0; o < headers.size(); o += 64)
+                m_readback.read(m_count_in.get() + o, std::min<unsigned int>(64, (unsigned int)headers.size() - o), headers.data() + o, "migration headers");
+            unsigned int most = 0;
             for (unsigned int r = 0; r < m_world; r++)
                 most = std::max(most, headers[2 * r + 1]);
-            if (most <= (long long)slot_rows)
+            if (most <= slot_rows)
                 break;
-            m_mig_slot_rows = 2 * (unsigned int)most; // the same decision on every rank: send again with room for all
+            m_mig_slot_rows = 2 * most; // the same decision on every rank: send again with room for all
             }
         for (unsigned int r = 0; r < m_world; r++)
             {
-            recv_counts[r] = (unsigned int)headers[2 * r];
+            recv_counts[r] = headers[2 * r];
             n_recv += recv_counts[r];
             }
         }
@@ -417,35 +419,101 @@ void CommunicatorGPU::exchangeGhosts(Scalar r_ghost)
     std::fill(m_send_rows.begin(), m_send_rows.end(), 0u);
     for (unsigned int k = 0; k < ndir; k++)
         m_send_rows[m_dir_dest[k]] += counters[1 + k];
-    // how many ghosts arrive from whom
-    m_count_out.upload(m_send_rows.data(), m_world);
-    const std::vector<unsigned int> one(m_world, 1);
-    m_transport->allToAll((uintptr_t)m_count_out.get(), one, (uintptr_t)m_count_in.get(), one, 4, 0);
-    m_count_in.download(m_recv_rows.data(), m_world);
-    n_count_exchanges++;
-    const unsigned int n_ghost = std::accumulate(m_recv_rows.begin(), m_recv_rows.end(), 0u);
-    m_pdata->setNGhosts(n_ghost);
     // one message per peer carries position, type and tag; the unpack kernel also sets the fields that are not
     // communicated
-    ensure(m_init_out, std::max(total, 1u));
-    ensure(m_init_in, std::max(n_ghost, 1u));
     hmd_pack_pos_args_t pa;
     std::memset(&pa, 0, sizeof(pa));
-    pa.d_out = m_init_out.get();
     pa.d_pos = m_pdata->pos();
     pa.d_send_idx = m_send_idx.get();
     pa.d_send_shift_id = m_send_dir.get();
     pa.d_shift_table = m_shift_table.get();
     pa.n_send = total;
-    abiCheck(hmd_pack_ghost_init(&pa, m_pdata->tag(), nullptr), "hmd_pack_ghost_init");
-    m_transport->allToAll((uintptr_t)m_init_out.get(), m_send_rows, (uintptr_t)m_init_in.get(), m_recv_rows, sizeof(Scalar4), 0);
     hmd_unpack_ghost_init_args_t u;
     std::memset(&u, 0, sizeof(u));
-    u.d_in = m_init_in.get();
-    u.n = n_ghost;
     u.first = N;
-    u.arrays = pdataArrays();
-    abiCheck(hmd_unpack_ghost_init(&u, nullptr), "hmd_unpack_ghost_init");
+    bool done = false;
+    if (m_use_ghost_slots && m_all_peers && m_have_prev_rows && 2 * m_world <= 64)
+        {
+        // Messages with room for somewhat more rows than the same pair of ranks exchanged last time -- a number both
+        // ends know -- each headed by its row count and by whether any message of its sender was too small.  Every
+        // rank hears from every other rank, so all of them learn all counts and reach the same verdict without an
+        // exchange of counts before the messages.
+        auto room = [this](unsigned int rows) { return rows + (m_ghost_room_div ? rows / m_ghost_room_div : 0u) + m_ghost_room_pad; };
+        hmd_ghost_slots_t so, si;
+        std::memset(&so, 0, sizeof(so));
+        std::memset(&si, 0, sizeof(si));
+        so.n_ranks = si.n_ranks = m_world;
+        std::vector<unsigned int> out_rows(m_world), in_rows(m_world);
+        unsigned int out_total = 0, in_total = 0;
+        for (unsigned int r = 0; r < m_world; r++)
+            {
+            so.off[r + 1] = so.off[r] + m_send_rows[r];
+            so.cap[r] = room(m_prev_send_rows[r]);
+            si.cap[r] = room(m_prev_recv_rows[r]);
+            so.row0[r] = out_total;
+            si.row0[r] = in_total;
+            out_rows[r] = so.cap[r] + 1;
+            in_rows[r] = si.cap[r] + 1;
+            out_total += out_rows[r];
+            in_total += in_rows[r];
+            if (m_send_rows[r] > so.cap[r])
+                so.flag = 1;
+            }
+        ensure(m_init_out, out_total);
+        ensure(m_init_in, in_total);
+        ensure(m_count_in, 2 * (size_t)m_world, 1.0, 0);
+        pa.d_out = m_init_out.get();
+        abiCheck(hmd_pack_ghost_init_slots(&pa, m_pdata->tag(), &so, nullptr), "hmd_pack_ghost_init_slots");
+        m_transport->allToAll((uintptr_t)m_init_out.get(), out_rows, (uintptr_t)m_init_in.get(), in_rows, sizeof(Scalar4), 0);
+        abiCheck(hmd_ghost_slot_headers(m_init_in.get(), &si, m_count_in.get(), nullptr), "hmd_ghost_slot_headers");
+        std::vector<unsigned int> words(2 * (size_t)m_world);
+        m_readback.read(m_count_in.get(), 2 * m_world, words.data(), "ghost message headers");
+        bool too_small = so.flag != 0;
+        for (unsigned int r = 0; r < m_world; r++)
+            too_small = too_small || words[2 * r + 1] != 0;
+        if (!too_small)
+            {
+            for (unsigned int r = 0; r < m_world; r++)
+                {
+                m_recv_rows[r] = words[2 * r];
+                si.off[r + 1] = si.off[r] + m_recv_rows[r];
+                }
+            const unsigned int n_ghost = si.off[m_world];
+            m_pdata->setNGhosts(n_ghost);
+            u.d_in = m_init_in.get();
+            u.n = n_ghost;
+            u.arrays = pdataArrays();
+            abiCheck(hmd_unpack_ghost_init_slots(&u, &si, nullptr), "hmd_unpack_ghost_init_slots");
+            done = true;
+            }
+        else
+            n_ghost_slot_overflows++; // every rank falls through to the exchange with counts
+        }
+    if (!done)
+        {
+        // how many ghosts arrive from whom
+        m_count_out.upload(m_send_rows.data(), m_world);
+        const std::vector<unsigned int> one(m_world, 1);
+        m_transport->allToAll((uintptr_t)m_count_out.get(), one, (uintptr_t)m_count_in.get(), one, 4, 0);
+        m_count_in.download(m_recv_rows.data(), m_world);
+        n_count_exchanges++;
+        const unsigned int n_ghost = std::accumulate(m_recv_rows.begin(), m_recv_rows.end(), 0u);
+        m_pdata->setNGhosts(n_ghost);
+        ensure(m_init_out, std::max(total, 1u));
+        ensure(m_init_in, std::max(n_ghost, 1u));
+        pa.d_out = m_init_out.get();
+        pa.d_pos = m_pdata->pos(); // (room for the ghosts may have moved the arrays)
+        abiCheck(hmd_pack_ghost_init(&pa, m_pdata->tag(), nullptr), "hmd_pack_ghost_init");
+        m_transport->allToAll((uintptr_t)m_init_out.get(), m_send_rows, (uintptr_t)m_init_in.get(), m_recv_rows, sizeof(Scalar4), 0);
+        u.d_in = m_init_in.get();
+        u.n = n_ghost;
+        u.arrays = pdataArrays();
+        abiCheck(hmd_unpack_ghost_init(&u, nullptr), "hmd_unpack_ghost_init");
+        }
+    m_prev_send_rows = m_send_rows;
+    m_prev_recv_rows = m_recv_rows;
+    m_have_prev_rows = true;
+    const unsigned int n_ghost = m_pdata->getNGhosts();
     buildVotePlan();
     hipCheck(hipMemsetAsync(m_pdata->rtag(), 0xff, sizeof(unsigned int) * std::max(m_pdata->getNGlobal(), 1u), nullptr), "clear rtag");
     abiCheck(hmd_build_rtag(m_pdata->rtag(), m_pdata->tag(), N + n_ghost, nullptr), "hmd_build_rtag");

@@ -1669,12 +1669,28 @@ class CommunicatorGPU : public Communicator
         {
         m_fixed_migrate = b && m_all_peers;
         }
+    //! ghost messages sized from the previous exchange instead of an exchange of counts (when all ranks are peers)
+    void setUseGhostSlots(bool b)
+        {
+        m_use_ghost_slots = b;
+        }
+    //! room of a ghost message: rows of the previous exchange + rows / div (div 0: nothing) + pad
+    void setGhostSlotRoom(unsigned int div, unsigned int pad)
+        {
+        m_ghost_room_div = div;
+        m_ghost_room_pad = pad;
+        }
+    //! forget the sizes of the previous ghost exchange (the next one exchanges counts)
+    void forgetGhostRows()
+        {
+        m_have_prev_rows = false;
+        }
     void setMigrateSlotRows(unsigned int n)
         {
         m_mig_slot_rows = std::max(n, 1u);
         }
     // statistics
-    uint64_t n_migrated_out = 0, n_migrated_in = 0, n_vote_exchanges = 0, n_count_exchanges = 0;
+    uint64_t n_migrated_out = 0, n_migrated_in = 0, n_vote_exchanges = 0, n_count_exchanges = 0, n_ghost_slot_overflows = 0;
     bool usesFixedMigrate() const
         {
         return m_fixed_migrate;
@@ -1720,7 +1736,9 @@ class CommunicatorGPU : public Communicator
     DeviceArray<unsigned char> m_send_dir;
     DeviceArray<Scalar4> m_init_out, m_init_in, m_pack_buf, m_vote_out, m_vote_in;
     unsigned int m_n_send = 0;
-    std::vector<unsigned int> m_send_rows, m_recv_rows, m_aug_send, m_aug_recv;
+    std::vector<unsigned int> m_send_rows, m_recv_rows, m_aug_send, m_aug_recv, m_prev_send_rows, m_prev_recv_rows;
+    bool m_use_ghost_slots = true, m_have_prev_rows = false;
+    unsigned int m_ghost_room_div = 8, m_ghost_room_pad = 64;
     DeviceArray<unsigned int> m_out_row, m_flag_rows;
     DeviceArray<int> m_in_map;
     unsigned int m_n_out = 0, m_n_in = 0;

@@ -220,6 +220,10 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("setUseVoteRows", &CommunicatorGPU::setUseVoteRows)
         .def("setFixedMigrate", &CommunicatorGPU::setFixedMigrate)
         .def("setMigrateSlotRows", &CommunicatorGPU::setMigrateSlotRows)
+        .def("setUseGhostSlots", &CommunicatorGPU::setUseGhostSlots)
+        .def("forgetGhostRows", &CommunicatorGPU::forgetGhostRows)
+        .def("setGhostSlotRoom", &CommunicatorGPU::setGhostSlotRoom)
+        .def_readonly("n_ghost_slot_overflows", &CommunicatorGPU::n_ghost_slot_overflows)
         .def_property_readonly("fixed_migrate", &CommunicatorGPU::usesFixedMigrate)
         .def_property_readonly("migrate_slot_rows", &CommunicatorGPU::getMigrateSlotRows)
         .def_readonly("n_migrated_out", &CommunicatorGPU::n_migrated_out)

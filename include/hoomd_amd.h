@@ -680,6 +680,33 @@ typedef struct
     } hmd_unpack_ghost_init_args_t;
 int hmd_unpack_ghost_init(const hmd_unpack_ghost_init_args_t* args, void* stream);
 
+/* The same first exchange in messages whose sizes both ends know beforehand, so that no exchange of counts precedes
+   it: the message to (from) rank r starts at row row0[r] of the buffer with a header row -- the number of data rows
+   the sender had for r in the low word of x, the sender's `flag` in the low word of y -- followed by room for
+   cap[r] data rows.  off: exclusive prefix sums of the data rows per rank (entries off[r] .. off[r + 1] - 1 of the
+   send list go to rank r; ghosts first + off[r] .. come from rank r); rows that do not fit their message are left
+   out, which the sender announces to every receiver through `flag`.  hmd_ghost_slot_headers copies the two words
+   of every incoming header to d_words[2 r], d_words[2 r + 1].  (The reference sizes its receive buffers from an
+   MPI exchange of counts before every ghost exchange, hoomd/CommunicatorGPU.cc:2396-2420; no counterpart.) */
+#define HMD_GHOST_SLOTS_MAX_RANKS 64
+typedef struct
+    {
+    unsigned int n_ranks;
+    unsigned int flag;
+    unsigned int off[HMD_GHOST_SLOTS_MAX_RANKS + 1];
+    unsigned int row0[HMD_GHOST_SLOTS_MAX_RANKS];
+    unsigned int cap[HMD_GHOST_SLOTS_MAX_RANKS];
+    } hmd_ghost_slots_t;
+int hmd_pack_ghost_init_slots(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, const hmd_ghost_slots_t* slots, void* stream);
+int hmd_ghost_slot_headers(const hmd_scalar4* d_in, const hmd_ghost_slots_t* slots, unsigned int* d_words, void* stream);
+int hmd_unpack_ghost_init_slots(const hmd_unpack_ghost_init_args_t* args, const hmd_ghost_slots_t* slots, void* stream);
+
+/* Words 0 and 1 of the header row of each of the n_ranks fixed-size migration messages in d_in (messages of
+   slot_rows + 1 rows, see hmd_migrate_pack): d_words[2 r] = particles in the message from rank r,
+   d_words[2 r + 1] = the largest count that rank sent to anyone.  One small kernel, so that the host reads the
+   headers like its other counters instead of through a strided copy.  No counterpart in the reference. */
+int hmd_migrate_slot_headers(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, unsigned int* d_words, void* stream);
+
 /* Row maps for hmd_pack_ghost_positions_vote / hmd_unpack_ghost_positions from the message sizes: every
    message to or from another rank gets one extra row (the vote) after its data rows.  send_off / recv_off:
    exclusive prefix sums of the data rows per rank (n_ranks + 1 entries).  Outputs: d_out_row[send_off[n_ranks]],

@@ -96,7 +96,8 @@ def main():
     if dd is not None:
         ex = dd.communicator
         stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges),
-                     fixed_migrate=int(ex.fixed_migrate), slot_rows=int(ex.migrate_slot_rows), count_exchanges=int(ex.n_count_exchanges))
+                     fixed_migrate=int(ex.fixed_migrate), slot_rows=int(ex.migrate_slot_rows), count_exchanges=int(ex.n_count_exchanges),
+                     ghost_slot_overflows=int(ex.n_ghost_slot_overflows))
         allstats = [None] * world
         dist.all_gather_object(allstats, stats)
     else:
@@ -106,7 +107,9 @@ def main():
                  dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
                  builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats],
                  vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats], overlapped=[a["overlapped"] for a in allstats],
-                 fixed_migrate=[a.get("fixed_migrate", 0) for a in allstats], slot_rows=[a.get("slot_rows", 0) for a in allstats])
+                 fixed_migrate=[a.get("fixed_migrate", 0) for a in allstats], slot_rows=[a.get("slot_rows", 0) for a in allstats],
+                 count_exchanges=[a.get("count_exchanges", 0) for a in allstats],
+                 ghost_slot_overflows=[a.get("ghost_slot_overflows", 0) for a in allstats])
     if dd is not None:
         dist.barrier()
         dist.destroy_process_group()

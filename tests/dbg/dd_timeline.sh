@@ -20,7 +20,7 @@ for f in glob.glob(out + "/**/*memory_copy_trace.csv", recursive=True):
 rows.sort()
 # the last rebuild: find the last nlist build kernel and print the 40 entries around it
 idx = max(i for i, r in enumerate(rows) if "nlist_pref" in r[2] or "nlist_b" in r[2])
-lo = max(0, idx - 34)
+lo = max(0, idx - 60)
 t0 = rows[lo][0]
 prev_end = t0
 for s, e, n in rows[lo: idx + 6]:

@@ -29,11 +29,20 @@ def test_decomposed_run_matches_single_domain(tmp_path, world, grid, sorter, n, 
     # Ranks that share a GPU keep the exchange stream at normal priority (chosen by the communicator: a high-priority
     # queue of one process that waits on a normal-priority queue can keep the queues of the other processes off the
     # hardware, two processes are enough for that).  The production priority runs in the one-rank test below.
+    # Ghost messages are sized from the previous exchange of the same pair of ranks.  One case gives them no spare room
+    # at all: whenever a message grows, the headers tell every rank, and all of them exchange counts first that time.
+    tight = world == 8 and not overlap
+    if tight:
+        env = dict(os.environ, HOOMD_AMD_GHOST_SLOT_ROOM="0,0")
     launch("_dd_worker.py", world, list(grid) + [out] + list(n) + [steps, sorter], timeout=60, env=env)
     a, b = np.load(ref), np.load(out)
     assert sum(b["N_local"]) == n[0] * n[1] * n[2] and all(g > 0 for g in b["n_ghosts"])
     assert sum(b["migrated"]) > 0
     assert min(b["fixed_migrate"]) == 1
+    # counts are exchanged for the first ghost layer of the run and after a message that was too small, never otherwise
+    assert len(set(b["ghost_slot_overflows"])) == 1 and len(set(b["count_exchanges"])) == 1
+    assert b["count_exchanges"][0] == 1 + b["ghost_slot_overflows"][0] and b["count_exchanges"][0] < min(b["builds"])
+    assert (b["ghost_slot_overflows"][0] > 0) == tight
     if env is not None:
         assert min(b["slot_rows"]) > 1 and len(set(b["slot_rows"])) == 1
     # every rank is every other rank's neighbor in these grids: the rebuild vote rode in the halo exchange
