@@ -40,6 +40,20 @@ template<class Ev> struct has_branch_free<Ev, decltype(std::declval<const Ev&>()
     static constexpr bool value = true;
     };
 
+// Optionally, too, the static evalUnshiftedBranchFree4(rsq[4], rcutsq[4], params[4], force_divr[4], pair_eng[4]): the same for four
+// pairs at once, which lets an evaluator share work between them (one reciprocal for four pairs in the LJ evaluator).
+template<class Ev, class = void> struct has_branch_free4
+    {
+    static constexpr bool value = false;
+    };
+template<class Ev>
+struct has_branch_free4<Ev, decltype(Ev::evalUnshiftedBranchFree4(std::declval<const double (&)[4]>(), std::declval<const double (&)[4]>(),
+                                                                 std::declval<const typename Ev::param_type* const (&)[4]>(), std::declval<double (&)[4]>(),
+                                                                 std::declval<double (&)[4]>()))>
+    {
+    static constexpr bool value = true;
+    };
+
 __device__ __forceinline__ unsigned int pf_xcd_remap(unsigned int b, unsigned int nb)
     {
     const unsigned int q = nb / 8, r = nb % 8, x = b % 8;
@@ -180,6 +194,36 @@ __device__ __forceinline__ void pf_pair(pf_accum& s, double dx, double dy, doubl
         s.vyy += dy * dy * f2;
         s.vyz += dy * dz * f2;
         s.vzz += dz * dz * f2;
+        }
+    }
+
+// Four pairs of one home particle through the evaluator's four-pair form (unshifted potential, no charges)
+template<class Ev, bool VIRIAL>
+__device__ __forceinline__ void pf_pair4(pf_accum& s, const double (&dx)[4], const double (&dy)[4], const double (&dz)[4], const double (&rcutsq)[4],
+                                         const typename Ev::param_type* const (&prm)[4])
+    {
+    double rsq[4], fdr[4], eng[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        rsq[m] = dx[m] * dx[m] + dy[m] * dy[m] + dz[m] * dz[m];
+    Ev::evalUnshiftedBranchFree4(rsq, rcutsq, prm, fdr, eng);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        {
+        s.fx += dx[m] * fdr[m];
+        s.fy += dy[m] * fdr[m];
+        s.fz += dz[m] * fdr[m];
+        s.pe += eng[m];
+        if (VIRIAL)
+            {
+            const double f2 = 0.5 * fdr[m];
+            s.vxx += dx[m] * dx[m] * f2;
+            s.vxy += dx[m] * dy[m] * f2;
+            s.vxz += dx[m] * dz[m] * f2;
+            s.vyy += dy[m] * dy[m] * f2;
+            s.vyz += dy[m] * dz[m] * f2;
+            s.vzz += dz[m] * dz[m] * f2;
+            }
         }
     }
 

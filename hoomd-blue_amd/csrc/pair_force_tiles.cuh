@@ -483,12 +483,42 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                 c.z[m] = *(volatile pft_lds_double*)(t + 64);
                 }
         };
+        // the evaluator's four-pair form where it exists (with the virial sums it would not fit the registers)
+#ifdef HMD_PFT_NO_BATCH4
+        constexpr bool BATCH4 = false;
+#else
+        constexpr bool BATCH4 = SHIFT == 0 && !VIRIAL && has_branch_free4<Ev>::value && (SINGLE_TYPE || TWO_TYPES);
+#endif
         auto pairs = [&](const quad& c)
         {
 #ifdef HMD_PFT_SKELETON
             acc.fx += c.x[0] + c.y[1] + c.z[2] + c.x[3];
             return;
 #endif
+            if constexpr (BATCH4)
+                {
+                // the four pairs of a chunk at once (they share work inside the evaluator)
+                double dx[4], dy[4], dz[4], rc[4];
+                const param_t* pp[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    {
+                    dx[m] = xi - c.x[m], dy[m] = yi - c.y[m], dz[m] = zi - c.z[m];
+                    if (SINGLE_TYPE)
+                        {
+                        rc[m] = rcutsq0;
+                        pp[m] = &p0;
+                        }
+                    else
+                        {
+                        const bool second = ttype[c.j[m] >> 3] != 0;
+                        rc[m] = second ? rc2[1] : rc2[0];
+                        pp[m] = second ? &prm2[1] : &prm2[0];
+                        }
+                    }
+                pf_pair4<Ev, VIRIAL>(acc, dx, dy, dz, rc, pp);
+                return;
+                }
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 {
@@ -524,11 +554,12 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
         // Rows are padded to a multiple of four entries with the dummy's slot; pieces past the end of a row hold
         // whatever was there: their lanes are switched off.  The tile reads of the next chunk are issued before the
         // arithmetic of the present one, so a wave does not sit idle through the LDS latency at every chunk.
-        // (only where the registers allow it without spilling: the plain potential without virials)
+        // (only where the registers allow it without spilling: the plain potential without virials, evaluated pair by
+        // pair; the four-pair form keeps four pairs in flight by itself and needs the registers)
 #ifdef HMD_PFT_NO_PIPE
         constexpr bool PIPELINED = false;
 #else
-        constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL && !TWO_TYPES);
+        constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL && !TWO_TYPES && !BATCH4);
 #endif
         quad qa;
         if (PIPELINED)
