@@ -66,6 +66,8 @@ __device__ __forceinline__ void hmd_st4(hmd_scalar4* p, double x, double y, doub
 // so the guarantee comes from the translation unit: every unit that uses these helpers for a
 // bit-exact result sets `#pragma clang fp contract(off)` before including this header and is
 // compiled with -ffp-contract=off (csrc/Makefile).  The macros only mark the places that rely on it.
+// The box helpers below also carry the pragma in their bodies, so they round the same way when a unit
+// that allows fused multiply-adds calls them (the integration pass that rides on the pair-force kernel).
 #define HMD_MUL(a, b) ((a) * (b))
 #define HMD_ADD(a, b) ((a) + (b))
 #define HMD_SUB(a, b) ((a) - (b))
@@ -73,6 +75,7 @@ __device__ __forceinline__ void hmd_st4(hmd_scalar4* p, double x, double y, doub
 // BoxDim::makeFraction (hoomd/BoxDim.h:260-268), products and sums rounded separately.
 __device__ __forceinline__ double3 hmd_make_fraction(const hmd_box_t& b, double x, double y, double z, const hmd_scalar3& gw)
     {
+#pragma clang fp contract(off)
     double dx = HMD_SUB(x, b.lo[0]);
     double dy = HMD_SUB(y, b.lo[1]);
     double dz = HMD_SUB(z, b.lo[2]);
@@ -92,6 +95,7 @@ __device__ __forceinline__ double3 hmd_make_fraction(const hmd_box_t& b, double 
 // equals the host form (:326-373) bit for bit: the image count is -1, 0 or +1 and L*count is exact.
 template<bool ORTHO> __device__ __forceinline__ void hmd_min_image(const hmd_box_t& b, double& x, double& y, double& z)
     {
+#pragma clang fp contract(off)
     if (b.periodic[2])
         {
         const double img = rint(HMD_MUL(z, b.Linv[2]));
@@ -119,6 +123,7 @@ template<bool ORTHO> __device__ __forceinline__ void hmd_min_image(const hmd_box
 // BoxDim::wrap with flags (0,0,0) (hoomd/BoxDim.h:391-458)
 __device__ __forceinline__ void hmd_wrap(const hmd_box_t& b, double& x, double& y, double& z, int& ix, int& iy, int& iz)
     {
+#pragma clang fp contract(off)
     double oy = (b.hi[1] + b.lo[1]) / 2.0;
     double oz = (b.hi[2] + b.lo[2]) / 2.0;
     if (!b.periodic[1])

@@ -9,6 +9,7 @@
 // following sum (the CPU path rounds every product and sum separately).
 #pragma clang fp contract(off)
 #include "common.cuh"
+#include "step_body.cuh"
 
 namespace
     {
@@ -100,63 +101,10 @@ template<bool CHECK, bool ORTHO, bool STEP_TWO = true> __global__ void __launch_
     if (g < a.one.group_size)
         {
         const unsigned int idx = a.one.d_group_members ? a.one.d_group_members[g] : g;
-        const double4 v = hmd_ld4(a.one.d_vel + idx);
-        const double4 p = hmd_ld4(a.one.d_pos + idx);
-        hmd_scalar3 acc;
-        double vx = v.x, vy = v.y, vz = v.z;
+        double4 f = make_double4(0, 0, 0, 0);
         if (STEP_TWO)
-            {
-            // ---- step two (t) ----
-            const double4 f = hmd_ld4(a.two.d_net_force + idx);
-            const double minv = 1.0 / v.w;
-            acc.x = HMD_MUL(f.x, minv);
-            acc.y = HMD_MUL(f.y, minv);
-            acc.z = HMD_MUL(f.z, minv);
-            const double hdt = HMD_MUL(0.5, a.two.deltaT);
-            vx = HMD_ADD(HMD_MUL(v.x, a.two.rescale_factor), HMD_MUL(hdt, acc.x));
-            vy = HMD_ADD(HMD_MUL(v.y, a.two.rescale_factor), HMD_MUL(hdt, acc.y));
-            vz = HMD_ADD(HMD_MUL(v.z, a.two.rescale_factor), HMD_MUL(hdt, acc.z));
-            if (a.two.d_accel)
-                a.two.d_accel[idx] = acc;
-            }
-        else
-            acc = a.one.d_accel[idx];
-        // ---- step one (t+1) ----
-        vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), a.one.rescale_factor);
-        vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), a.one.rescale_factor);
-        vz = HMD_MUL(HMD_ADD(vz, HMD_MUL(HMD_MUL(0.5, acc.z), a.one.deltaT)), a.one.rescale_factor);
-        double x = HMD_ADD(p.x, HMD_MUL(a.one.deltaT, vx));
-        double y = HMD_ADD(p.y, HMD_MUL(a.one.deltaT, vy));
-        double z = HMD_ADD(p.z, HMD_MUL(a.one.deltaT, vz));
-        // few particles cross the box boundary in a step: touch the image only for those
-        hmd_int3 dimg = {0, 0, 0};
-        hmd_wrap(a.one.box, x, y, z, dimg.x, dimg.y, dimg.z);
-        hmd_st4(a.one.d_pos + idx, x, y, z, p.w);
-        hmd_st4(a.one.d_vel + idx, vx, vy, vz, v.w);
-        if (dimg.x | dimg.y | dimg.z)
-            {
-            hmd_int3 img = a.one.d_image[idx];
-            img.x += dimg.x;
-            img.y += dimg.y;
-            img.z += dimg.z;
-            a.one.d_image[idx] = img;
-            }
-        if (a.d_cpos)
-            hmd_st4(a.d_cpos + a.d_slot_of[idx], x, y, z, p.w);
-        // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
-        if (CHECK)
-            {
-            const double4 last = hmd_ld4(a.check.d_last_pos + idx);
-            double dx = HMD_SUB(x, HMD_MUL(a.check.lambda.x, last.x));
-            double dy = HMD_SUB(y, HMD_MUL(a.check.lambda.y, last.y));
-            double dz = HMD_SUB(z, HMD_MUL(a.check.lambda.z, last.z));
-            hmd_min_image<ORTHO>(a.check.box, dx, dy, dz);
-            const double rmin = a.check.d_rcut_max[hmd_double_as_uint(p.w)];
-            const double rmax = HMD_ADD(rmin, a.check.r_buff);
-            const double delta_max = HMD_SUB(HMD_MUL(rmax, a.check.lambda_min), rmin) / 2.0;
-            const double maxsq = (delta_max > 0) ? HMD_MUL(delta_max, delta_max) : 0.0;
-            moved = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz)) >= maxsq;
-            }
+            f = hmd_ld4(a.two.d_net_force + idx);
+        moved = hmd_fused_step_particle<ORTHO, STEP_TWO>(a, idx, f, CHECK);
         }
     if (CHECK)
         {

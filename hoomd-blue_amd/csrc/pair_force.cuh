@@ -228,8 +228,9 @@ __device__ __forceinline__ void pf_pair4(pf_accum& s, const double (&dx)[4], con
     }
 
 // fold the TPP lanes of a particle and store force (w = half the pair energy) and virial
+// (returns the force, complete in the writer's lane)
 template<bool VIRIAL, int TPP>
-__device__ __forceinline__ void pf_finish(pf_accum& s, const hmd_pair_args_t& a, unsigned int idx, bool writer)
+__device__ __forceinline__ double4 pf_finish(pf_accum& s, const hmd_pair_args_t& a, unsigned int idx, bool writer)
     {
     const double fx = pf_reduce<TPP>(s.fx), fy = pf_reduce<TPP>(s.fy), fz = pf_reduce<TPP>(s.fz);
     const double pe = 0.5 * pf_reduce<TPP>(s.pe);
@@ -249,6 +250,7 @@ __device__ __forceinline__ void pf_finish(pf_accum& s, const hmd_pair_args_t& a,
             a.d_virial[5 * a.virial_pitch + idx] = vzz;
             }
         }
+    return make_double4(fx, fy, fz, pe);
     }
 
 constexpr int PF_VEC = 4; // neighbors handled per lane per loop trip (one 16-byte index load)

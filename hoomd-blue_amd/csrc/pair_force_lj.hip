@@ -29,3 +29,20 @@ extern "C" int hmd_compute_pair_forces_lj_tiles(const hmd_pair_args_t* args, con
     {
     return hmd::launch_pair_forces_tiles<EvaluatorPairLJ>(args, geom, d_tile_nlist, static_cast<const EvaluatorPairLJ::param_type*>(d_params), stream);
     }
+
+extern "C" int hmd_compute_pair_forces_lj_tiles_step(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom, const unsigned short* d_tile_nlist,
+                                                   const hmd_lj_params_t* d_params, const hmd_fused_step_args_t* step, void* stream)
+    {
+    HMD_REQUIRE(step, HMD_ERR_INVALID_ARGUMENT, "pair forces (tiles) with the integration pass: step is required");
+    return hmd::launch_pair_forces_tiles<EvaluatorPairLJ>(args, geom, d_tile_nlist, static_cast<const EvaluatorPairLJ::param_type*>(d_params), stream, step);
+    }
+
+extern "C" int hmd_pair_forces_tiles_step_supported(const hmd_pair_args_t* args, const hmd_fused_step_args_t* step)
+    {
+    HMD_REQUIRE(args && step, HMD_ERR_INVALID_ARGUMENT, "hmd_pair_forces_tiles_step_supported: args and step are required");
+    const char* why = nullptr;
+    if (hmd::pft_step_supported(*args, *step, &why))
+        return HMD_OK;
+    hmd_set_error(why);
+    return HMD_ERR_UNSUPPORTED;
+    }

@@ -14,7 +14,9 @@
 #define HMD_PAIR_FORCE_TILES_CUH
 
 #include "pair_force.cuh"
+#include "step_body.cuh"
 #include "tile.cuh"
+#include <cstring>
 
 namespace hmd
     {
@@ -84,6 +86,163 @@ constexpr int PFT_WAVES = PFT_THREADS / 64;
 constexpr int PFT_TRIPS = 4;
 static_assert(TR_X == 4 && TR_Y == 4 && TR_Z == 4 && PFT_WAVES == 4 && TL_NH == 8, "staging maps (lane / 16, wave, trip) to the cells of a 4x4x4 region");
 
+// The integration pass that may ride on the kernel, in the form the kernel carries it: an orthorhombic box periodic
+// in all three directions that has not changed since the neighbor list was built, no velocity rescaling -- the case
+// of an NVE run (the launcher declines everything else).  The kernel argument is copied to LDS once per workgroup and
+// read from there where a home particle is finished: as scalar registers these forty values would have to stay
+// resident through the whole pair loop, which has none to spare.
+struct pft_step_t
+    {
+    double dt;
+    double lo[3], hi[3], L[3], Linv[3];
+    double r_buff;
+    hmd_scalar4* d_vel;
+    hmd_scalar4* d_pos;
+    hmd_int3* d_image;
+    const unsigned int* d_slot_of;
+    hmd_scalar4* d_cpos;
+    const hmd_scalar4* d_last_pos;
+    const double* d_rcut_max;
+    unsigned int* d_result;
+    unsigned int checkn, check;
+    };
+
+// can the pass ride?  (the conditions above; `why` receives the first one that fails)
+static inline bool pft_step_supported(const hmd_pair_args_t& a, const hmd_fused_step_args_t& t, const char** why)
+    {
+    const char* w = nullptr;
+    if (a.compute_virial || a.block_window_mode != 0)
+        w = "not with virials or a window of blocks";
+    else if (!(t.one.d_pos && t.one.d_vel && t.one.d_image && t.one.d_vel == t.two.d_vel))
+        w = "one.d_pos, one.d_vel (= two.d_vel) and one.d_image are required";
+    else if (t.one.d_group_members || t.two.d_group_members || t.one.group_size != a.N || t.two.group_size != a.N || t.one.use_limit)
+        w = "the group must be every particle, without a displacement limit";
+    else if (t.two.d_accel)
+        w = "the accelerations are not stored (two.d_accel must be null)";
+    else if (t.one.rescale_factor != 1.0 || t.two.rescale_factor != 1.0 || t.one.deltaT != t.two.deltaT)
+        w = "no velocity rescaling, one time step length";
+    else if (!hmd_box_is_ortho(t.one.box) || !(t.one.box.periodic[0] && t.one.box.periodic[1] && t.one.box.periodic[2]))
+        w = "the box must be orthorhombic and periodic in all directions";
+    else if (t.check.d_result
+             && (std::memcmp(&t.one.box, &t.check.box, sizeof(hmd_box_t)) != 0 || t.check.lambda.x != 1.0 || t.check.lambda.y != 1.0
+                 || t.check.lambda.z != 1.0 || t.check.lambda_min != 1.0))
+        w = "the box must be the one the neighbor list was built in";
+    else if (t.check.d_result && !(t.check.d_last_pos && t.check.d_rcut_max && t.check.N == a.N))
+        w = "the distance check needs d_last_pos, d_rcut_max and N";
+    if (why)
+        *why = w;
+    return w == nullptr;
+    }
+
+// One home particle's share of the pass: hmd_fused_step_particle<true, true> (step_body.cuh) with the factors that are
+// one and the tilts that are zero left out -- x * 1.0, x - 0.0 and x + 0.0 * y are exact, so the bits are the same.
+typedef const __attribute__((address_space(3))) pft_step_t pft_step_lds;
+typedef double pft_v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) pft_v4d pft_g_double4;
+typedef __attribute__((address_space(1))) int pft_g_int;
+typedef __attribute__((address_space(1))) const unsigned int pft_g_cuint;
+typedef __attribute__((address_space(1))) const double pft_g_cdouble;
+// Everything the pass reads is fetched first, in one memory round trip (the index of the particle is all the addresses
+// need; with one particle type so is the type), the arithmetic and the stores follow.
+template<bool SINGLE_TYPE>
+__device__ __forceinline__ bool pft_step_particle(pft_step_lds& S, unsigned int idx, double fx, double fy, double fz)
+    {
+#pragma clang fp contract(off)
+    pft_g_double4* d_vel = (pft_g_double4*)S.d_vel;
+    pft_g_double4* d_pos = (pft_g_double4*)S.d_pos;
+    const bool check = S.check != 0u;
+    const pft_v4d v = d_vel[idx];
+    const pft_v4d p = d_pos[idx];
+    const unsigned int slot = ((pft_g_cuint*)S.d_slot_of)[idx];
+    pft_v4d last = {0.0, 0.0, 0.0, 0.0};
+    double rmin = 0.0;
+    if (check)
+        {
+        last = ((const pft_g_double4*)S.d_last_pos)[idx];
+        if (SINGLE_TYPE)
+            rmin = ((pft_g_cdouble*)S.d_rcut_max)[0];
+        }
+    const double dt = S.dt;
+    // ---- step two (t) ----
+    // (1 / 1 is 1: when every particle the wave is finishing has unit mass the division, a dozen instructions, is left out)
+    double minv = 1.0;
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(v.w != 1.0) != 0ull)))
+        minv = 1.0 / v.w;
+    const double ax = HMD_MUL(fx, minv), ay = HMD_MUL(fy, minv), az = HMD_MUL(fz, minv);
+    const double hdt = HMD_MUL(0.5, dt);
+    double vx = HMD_ADD(v.x, HMD_MUL(hdt, ax));
+    double vy = HMD_ADD(v.y, HMD_MUL(hdt, ay));
+    double vz = HMD_ADD(v.z, HMD_MUL(hdt, az));
+    // ---- step one (t+1) ----
+    vx = HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, ax), dt));
+    vy = HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, ay), dt));
+    vz = HMD_ADD(vz, HMD_MUL(HMD_MUL(0.5, az), dt));
+    double x = HMD_ADD(p.x, HMD_MUL(dt, vx));
+    double y = HMD_ADD(p.y, HMD_MUL(dt, vy));
+    double z = HMD_ADD(p.z, HMD_MUL(dt, vz));
+    // BoxDim::wrap (hoomd/BoxDim.h:391-458) without tilt
+    int ix = 0, iy = 0, iz = 0;
+        {
+        const double L0 = S.L[0], L1 = S.L[1], L2 = S.L[2];
+        if (x >= S.hi[0])
+            {
+            x = HMD_SUB(x, L0);
+            ix++;
+            }
+        else if (x < S.lo[0])
+            {
+            x = HMD_ADD(x, L0);
+            ix--;
+            }
+        if (y >= S.hi[1])
+            {
+            y = HMD_SUB(y, L1);
+            iy++;
+            }
+        else if (y < S.lo[1])
+            {
+            y = HMD_ADD(y, L1);
+            iy--;
+            }
+        if (z >= S.hi[2])
+            {
+            z = HMD_SUB(z, L2);
+            iz++;
+            }
+        else if (z < S.lo[2])
+            {
+            z = HMD_ADD(z, L2);
+            iz--;
+            }
+        }
+    d_pos[idx] = pft_v4d {x, y, z, p.w};
+    d_vel[idx] = pft_v4d {vx, vy, vz, v.w};
+    ((pft_g_double4*)S.d_cpos)[slot] = pft_v4d {x, y, z, p.w};
+    if (ix | iy | iz)
+        {
+        pft_g_int* d_image = (pft_g_int*)S.d_image + 3u * (size_t)idx;
+        d_image[0] += ix;
+        d_image[1] += iy;
+        d_image[2] += iz;
+        }
+    // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
+    bool moved = false;
+    if (check)
+        {
+        if (!SINGLE_TYPE)
+            rmin = ((pft_g_cdouble*)S.d_rcut_max)[hmd_double_as_uint(p.w)];
+        double dx = HMD_SUB(x, last.x), dy = HMD_SUB(y, last.y), dz = HMD_SUB(z, last.z);
+        dz = HMD_SUB(dz, HMD_MUL(S.L[2], rint(HMD_MUL(dz, S.Linv[2]))));
+        dy = HMD_SUB(dy, HMD_MUL(S.L[1], rint(HMD_MUL(dy, S.Linv[1]))));
+        dx = HMD_SUB(dx, HMD_MUL(S.L[0], rint(HMD_MUL(dx, S.Linv[0]))));
+        const double rmax = HMD_ADD(rmin, S.r_buff);
+        const double delta_max = HMD_SUB(rmax, rmin) / 2.0;
+        const double maxsq = (delta_max > 0) ? HMD_MUL(delta_max, delta_max) : 0.0;
+        moved = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz)) >= maxsq;
+        }
+    return moved;
+    }
+
 // what the workgroup shares besides the tile and the home table
 struct pft_tables
     {
@@ -91,6 +250,7 @@ struct pft_tables
     unsigned int hcum[TL_NH + 1]; // exclusive prefix of the sizes of the home cells, in home-cell order; hcum[8] = home particles
     unsigned int word;            // the predicate word, read once for the whole workgroup
     unsigned int pad_;
+    pft_step_t step;              // what the integration pass needs, when it rides on the kernel
     };
 constexpr size_t PFT_TABLES = (sizeof(pft_tables) + 15) / 16 * 16;
 
@@ -141,10 +301,15 @@ __device__ __forceinline__ pft_axis pft_axis_cell(int c, int dim, bool periodic)
     return r;
     }
 
-template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false>
+// STEP: the integration pass rides on the kernel.  The lane that holds a home particle's finished force goes straight
+// on with the second half of the time step, the first half of the next one, the distance check of the new position
+// and the slot-ordered copy (step_body.cuh) -- the force never makes the round trip through memory to a separate
+// pass, and a time step is this one kernel.  The new positions go to the particle array, which this kernel does not
+// read, and to a second slot-ordered buffer (st.d_cpos must not be g.d_cpos: other workgroups are still staging from it).
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false, bool STEP = false>
 __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params,
-                            pft_launch_t lp)
+                            pft_launch_t lp, pft_step_t st)
     {
     typedef typename Ev::param_type param_t;
     // All LDS of this kernel is dynamic and the tile comes first, so that the tile starts at LDS
@@ -184,6 +349,8 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                                __HIP_MEMORY_SCOPE_SYSTEM);
         T.word = word;
         }
+    if (STEP && threadIdx.x == 64)
+        T.step = st;
     const unsigned int np = a.ntypes * a.ntypes;
     // (the 8-byte home entries end on a multiple of eight: pft_home_bytes pads to 16 for the tables of doubles behind them)
     double* s_rcutsq = reinterpret_cast<double*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES + pft_home_bytes(g.cli.w));
@@ -425,6 +592,9 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
 #endif
     const unsigned int s4 = lane % PFT_T, gl = lane / PFT_T;
     const unsigned int ngroups = (H + TL_GROUP - 1) / TL_GROUP;
+    // (STEP) the particle whose finished force this lane keeps for the integration pass, and the wave's count of groups
+    double kfx = 0.0, kfy = 0.0, kfz = 0.0;
+    unsigned int kidx = 0xffffffffu, kept = 0;
     const unsigned int P = g.row_pieces;
     // piece p of group j of this block: 64 uint2 (four entries each) at rows[(j * P + p) * 64], lane order
     const uint2* rows = reinterpret_cast<const uint2*>(d_tile_nlist) + (size_t)grp0 * P * 64 + lane;
@@ -607,7 +777,40 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                     }
                 }
             }
-        pf_finish<VIRIAL, PFT_T>(acc, a, e.idx, h < H && e.idx < a.N && s4 == 0);
+        const bool writer = h < H && e.idx < a.N && s4 == 0;
+        const double4 f = pf_finish<VIRIAL, PFT_T>(acc, a, e.idx, writer);
+        if constexpr (STEP)
+            {
+            // The finished force is complete in all four lanes of the home particle: the lane whose number among the
+            // four equals the count of groups this wave has finished keeps it, so after four groups every lane of the
+            // wave holds one particle and the integration pass runs once with all lanes busy (flush below), instead
+            // of sixteen lanes at the end of every group.
+            if (s4 == (kept & 3u))
+                {
+                kfx = f.x;
+                kfy = f.y;
+                kfz = f.z;
+                kidx = (h < H && e.idx < a.N) ? e.idx : 0xffffffffu;
+                }
+            kept++;
+            }
+    };
+    auto flush = [&]()
+    {
+        if constexpr (STEP)
+            {
+            // (the offset passes through an empty asm statement so that the parameters are read here, in one batch, and
+            // not ahead of the loop, where they would sit in registers all the way)
+            unsigned int soff = tile_len * 8u + (unsigned int)offsetof(pft_tables, step);
+            asm volatile("" : "+v"(soff));
+            pft_step_lds& S = *(pft_step_lds*)(size_t)soff;
+            bool moved = false;
+            if (kidx != 0xffffffffu)
+                moved = pft_step_particle<SINGLE_TYPE>(S, kidx, kfx, kfy, kfz);
+            if (__ballot(moved) && lane == 0)
+                atomicMax(S.d_result, S.checkn);
+            kidx = 0xffffffffu;
+            }
     };
     uint2 b0[PFT_PRE], b1[PFT_PRE];
     unsigned int grp = wave;
@@ -625,7 +828,11 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             fetch(grp + PFT_WAVES, b0);
         process(grp, b1);
         grp += PFT_WAVES;
+        if (STEP && (kept & 3u) == 0u)
+            flush();
         }
+    if (STEP && (kept & 3u) != 0u)
+        flush();
     }
 
 template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned int ntypes, unsigned int cell_Nmax)
@@ -636,10 +843,34 @@ template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned
     return (b + 15) / 16 * 16;
     }
 
-template<class Ev, unsigned int SHIFT, bool VIRIAL>
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool STEP = false>
 int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsigned short* d_tile_nlist,
-                const typename Ev::param_type* d_params, hipStream_t s)
+                const typename Ev::param_type* d_params, hipStream_t s, const hmd_fused_step_args_t* step = nullptr)
     {
+    pft_step_t st;
+    memset(&st, 0, sizeof(st));
+    if (STEP)
+        {
+        st.dt = step->one.deltaT;
+        for (int d = 0; d < 3; d++)
+            {
+            st.lo[d] = step->one.box.lo[d];
+            st.hi[d] = step->one.box.hi[d];
+            st.L[d] = step->one.box.L[d];
+            st.Linv[d] = step->one.box.Linv[d];
+            }
+        st.r_buff = step->check.r_buff;
+        st.d_vel = step->one.d_vel;
+        st.d_pos = step->one.d_pos;
+        st.d_image = step->one.d_image;
+        st.d_slot_of = step->d_slot_of;
+        st.d_cpos = step->d_cpos;
+        st.d_last_pos = step->check.d_last_pos;
+        st.d_rcut_max = step->check.d_rcut_max;
+        st.d_result = step->check.d_result;
+        st.checkn = step->check.checkn;
+        st.check = step->check.d_result != nullptr;
+        }
     const size_t lds = pft_lds_bytes<Ev>(g.capacity, a.ntypes, g.cli.w);
     unsigned int nblocks = tile_num_blocks(g.ci);
     if (a.block_window_mode)
@@ -660,25 +891,26 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
     lp.inv_dim[2] = 1.0 / (double)g.ci.d;
     if (a.ntypes == 1)
         {
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>, lds);
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, STEP>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
     else if (a.ntypes == 2)
         {
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true>, lds);
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, STEP>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
     else
         {
-        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false>, lds);
-        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp);
+        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, STEP>, lds);
+        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
     return hmd_launch_status();
     }
 
+// step: the integration pass to carry (hmd_fused_step_args_t as for hmd_nve_step_two_one_check), or null
 template<class Ev>
 int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom, const unsigned short* d_tile_nlist,
-                             const typename Ev::param_type* d_params, void* stream)
+                             const typename Ev::param_type* d_params, void* stream, const hmd_fused_step_args_t* step = nullptr)
     {
     HMD_REQUIRE(args && geom && d_tile_nlist && d_params, HMD_ERR_INVALID_ARGUMENT,
                 "pair forces (tiles): args, geom, d_tile_nlist and d_params are required");
@@ -715,10 +947,33 @@ int launch_pair_forces_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t*
         }
     HMD_REQUIRE(a.threads_per_particle == 0 || a.threads_per_particle == PFT_T, HMD_ERR_INVALID_ARGUMENT,
                 "pair forces (tiles): threads_per_particle must be 0 or 4");
+    if (step)
+        {
+        const char* why = nullptr;
+        if (!pft_step_supported(a, *step, &why))
+            {
+            static thread_local char msg[256];
+            snprintf(msg, sizeof(msg), "pair forces (tiles) with the integration pass: %s", why);
+            hmd_set_error(msg);
+            return HMD_ERR_UNSUPPORTED;
+            }
+        HMD_REQUIRE(step->d_cpos && step->d_slot_of && step->d_cpos != g.d_cpos, HMD_ERR_INVALID_ARGUMENT,
+                    "pair forces (tiles) with the integration pass: d_slot_of and a d_cpos other than geom.d_cpos are required");
+        }
     if (a.N == 0)
         return HMD_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vir = a.compute_virial != 0;
+    if (step)
+        switch (a.shift_mode)
+            {
+        case 0:
+            return pft_launch2<Ev, 0, false, true>(a, g, d_tile_nlist, d_params, s, step);
+        case 1:
+            return pft_launch2<Ev, 1, false, true>(a, g, d_tile_nlist, d_params, s, step);
+        default:
+            return pft_launch2<Ev, 2, false, true>(a, g, d_tile_nlist, d_params, s, step);
+            }
     switch (a.shift_mode)
         {
     case 0:

@@ -306,6 +306,8 @@ _SIGNATURES = {
     "hmd_nlist_tiles_to_rows": (C.c_int, [C.POINTER(TilesToRowsArgs), vp]),
     "hmd_compute_pair_forces_lj_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
     "hmd_compute_pair_forces_example_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
+    "hmd_compute_pair_forces_lj_tiles_step": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, C.POINTER(FusedStepArgs), vp]),
+    "hmd_pair_forces_tiles_step_supported": (C.c_int, [C.POINTER(PairArgs), C.POINTER(FusedStepArgs)]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -304,6 +304,47 @@ def pair_forces_tiles(evaluator, pos, N, box, tl, params, rcutsq, ronsq=None, sh
     return force, virial
 
 
+def pair_forces_tiles_step(pos, vel, image, N, box, tl, params, rcutsq, dt, last_pos=None, rcut_max=None, r_buff=0.0, checkn=1, shift_mode=0,
+                           skip=None):
+    """hmd_compute_pair_forces_lj_tiles_step: the tile pair force with the second half step, the next first half step, the
+    distance check and the slot-ordered copy riding on it.  pos, vel and image are updated in place; returns (force, the
+    new slot-ordered positions, flag word).  skip: (flag tensor, value) switches the launch off when flag == value."""
+    dev = pos.device
+    prm = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
+    rc = torch.as_tensor(np.asarray(rcutsq, dtype=np.float64), device=dev).contiguous()
+    nt = rc.shape[0]
+    ro = torch.zeros((nt, nt), dtype=torch.float64, device=dev)
+    force = torch.full((pos.shape[0], 4), float("nan"), dtype=torch.float64, device=dev)
+    a = _abi.PairArgs()
+    a.d_force, a.N, a.n_max, a.d_pos, a.box = ptr(force), N, pos.shape[0], ptr(pos), box
+    a.d_n_neigh, a.d_nlist, a.d_head_list = ptr(tl["n_neigh"]), None, ptr(tl["head"])
+    a.d_rcutsq, a.d_ronsq, a.size_neigh_list, a.ntypes = ptr(rc), ptr(ro), tl["tiles"].numel(), nt
+    a.shift_mode, a.compute_virial = shift_mode, 0
+    if skip is not None:
+        a.d_skip_flag, a.skip_value = ptr(skip[0]), skip[1]
+    geom = _abi.TileGeom.from_buffer_copy(tl["geom"])
+    cpos = tile_refresh(pos, tl)
+    cpos_new = torch.full_like(cpos, float("nan"))
+    geom.d_cpos, geom.d_slot_meta = ptr(cpos), ptr(tl["slot_meta"])
+    geom.capacity = max(int(tl["overflow"][1].item()), 1)
+    s = _abi.FusedStepArgs()
+    s.two.d_vel, s.two.d_net_force, s.two.group_size, s.two.deltaT, s.two.rescale_factor = ptr(vel), ptr(force), N, float(dt), 1.0
+    s.one.d_pos, s.one.d_vel, s.one.d_image = ptr(pos), ptr(vel), ptr(image)
+    s.one.group_size, s.one.box, s.one.rescale_factor, s.one.deltaT = N, box, 1.0, float(dt)
+    res = None
+    if last_pos is not None:
+        res = torch.zeros(1, dtype=torch.int32, device=dev)
+        rcm = torch.as_tensor(np.asarray(rcut_max, dtype=np.float64), device=dev)
+        c = s.check
+        c.d_result, c.d_last_pos, c.d_pos, c.N, c.box = ptr(res), ptr(last_pos), ptr(pos), N, box
+        c.d_rcut_max, c.r_buff, c.ntypes, c.lambda_min, c.lam, c.checkn = ptr(rcm), float(r_buff), rcm.numel(), 1.0, _s3((1.0, 1.0, 1.0)), checkn
+    s.d_slot_of, s.d_cpos = ptr(tl["slot_of"]), ptr(cpos_new)
+    check(_abi.lib.hmd_pair_forces_tiles_step_supported(C.byref(a), C.byref(s)), "hmd_pair_forces_tiles_step_supported")
+    check(_abi.lib.hmd_compute_pair_forces_lj_tiles_step(C.byref(a), C.byref(geom), ptr(tl["tiles"]), ptr(prm), C.byref(s), _stream(pos)),
+          "hmd_compute_pair_forces_lj_tiles_step")
+    return force, cpos_new, (int(res.item()) if res is not None else None)
+
+
 def bond_table(tag, rtag, N, tag_n_bonds, tag_blist):
     """Per-particle bond table in index order from the one keyed by tag (hmd_update_bond_table).
     tag_blist: (max_bonds, n_tags, 2) int32 of (partner tag, bond type)."""

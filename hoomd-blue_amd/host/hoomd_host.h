@@ -368,6 +368,28 @@ class ParticleData
         return m_check_hook;
         }
 
+    //! The integrator's offer to the force compute: take the second half of this time step and the first half of the
+    //! next one into the force kernel (hmd_compute_pair_forces_lj_tiles_step).  The source fills two / one of the
+    //! arguments for forces of `timestep` and says whether the offer stands; a force compute that has run the pass
+    //! says so with notifyStepRiderDone(timestep), and the integrator skips its own pass.
+    typedef std::function<bool(hmd_fused_step_args_t&, uint64_t)> StepRiderSource;
+    void setStepRiderSource(StepRiderSource s)
+        {
+        m_rider_source = s;
+        }
+    const StepRiderSource& getStepRiderSource() const
+        {
+        return m_rider_source;
+        }
+    void notifyStepRiderDone(uint64_t timestep)
+        {
+        m_rider_done_tstep = timestep;
+        }
+    uint64_t getStepRiderDone() const
+        {
+        return m_rider_done_tstep;
+        }
+
     //! when a single force compute feeds the integrator its force array IS the net force
     void aliasNetForce(Scalar4* p)
         {
@@ -461,6 +483,8 @@ class ParticleData
     DeviceArray<Scalar> m_charge, m_diameter, m_net_virial, m_alt1;
     Scalar4* m_net_force_alias = nullptr;
     DisplacementCheckHook m_check_hook;
+    StepRiderSource m_rider_source;
+    uint64_t m_rider_done_tstep = ~0ull;
     bool m_accel_set = false;
     unsigned int m_flags = 0;
     Scalar m_external_energy = 0;
@@ -983,6 +1007,17 @@ class NeighborListGPUBinned : public Compute
     //! copy the current positions (owned and ghost) into cell-list slot order for the tile force kernel
     void refreshTilePositions();
     void offerFusedPass(hmd_fused_step_args_t& a, uint64_t timestep);
+    //! the same offer to a pass that rides on the force kernel of the tile path: the new positions go to the second
+    //! slot-ordered buffer (the kernel is still staging from the first); false when the tile path is not in use
+    bool offerStepRider(hmd_fused_step_args_t& a, uint64_t timestep);
+    //! the kernel that carried the pass has run (it was not switched off): the second buffer is the current one now
+    void commitStepRider(uint64_t timestep);
+    //! the offer was not used after all: the check of `timestep` has not been launched
+    void withdrawStepRider(uint64_t timestep)
+        {
+        if (m_prelaunched_tstep == timestep)
+            m_prelaunched_tstep = ~0ull;
+        }
     //! Called from compute() right after a distance check has been queued and before the host waits for
     //! its result, with the device flag and the value it takes when the list is stale: a consumer may
     //! queue work that is only valid for a fresh list, predicated on the flag.
@@ -1076,7 +1111,7 @@ class NeighborListGPUBinned : public Compute
     void reallocatePerParticle();
     void ensureRows();
     bool tilesUsable(unsigned int& capacity);
-    void fillCheckArgs(hmd_nlist_check_args_t& a);
+    void fillCheckArgs(hmd_nlist_check_args_t& a, bool fresh = true);
     bool offerCheck(hmd_nlist_check_args_t& a, uint64_t timestep);
 
     std::shared_ptr<CellListGPU> m_cl;
@@ -1131,6 +1166,7 @@ class NeighborListGPUBinned : public Compute
     unsigned int m_row_pieces = 1;           // 16-entry pieces every tile row has room for
     DeviceArray<unsigned int> m_slot_of;   // particle index -> cell-list slot
     DeviceArray<Scalar4> m_cpos;           // positions in slot order, refreshed before each force launch
+    DeviceArray<Scalar4> m_cpos_alt;       // where a pass riding on the force kernel puts the next step's positions
     DeviceArray<hmd_uint4> m_slot_meta;    // per slot: particle index, n_neigh, row offset / 4
 
     // exclusions
@@ -1448,9 +1484,30 @@ class IntegratorTwoStep
         {
         m_request_pressure = b;
         }
+    //! Will update(timestep + 1) follow this update() with nothing in between (no sorter, no end of the run)?  Only then
+    //! may the force kernel of this step run the half steps around it (the run loop says so before every update).
+    void setLookahead(bool b)
+        {
+        m_lookahead = b;
+        }
+    //! switch for the half steps riding on the force kernel (on by default; tests compare both ways)
+    void setStepRider(bool b)
+        {
+        m_rider_enabled = b;
+        }
+    bool getStepRider() const
+        {
+        return m_rider_enabled;
+        }
+    //! time steps whose half steps ran inside the force kernel
+    uint64_t getNumRiderSteps() const
+        {
+        return m_n_rider_steps;
+        }
 
     private:
     void computeAccelerations(uint64_t timestep);
+    bool fillStepRider(hmd_fused_step_args_t& a, uint64_t timestep);
     std::shared_ptr<SystemDefinition> m_sysdef;
     std::shared_ptr<ParticleData> m_pdata;
     Scalar m_deltaT;
@@ -1460,6 +1517,11 @@ class IntegratorTwoStep
     bool m_pending_two = false;       // step two of m_pending_tstep has not run yet
     uint64_t m_pending_tstep = 0;
     bool m_fuse = true;
+    bool m_lookahead = false, m_rider_enabled = true;
+    bool m_rider_armed = false;          // the offer to the force compute stands for the force computation in progress
+    uint64_t m_rider_tstep = 0;          // ... of this time step
+    uint64_t m_step_one_done_for = ~0ull; // time step whose first half step already ran inside the previous force kernel
+    uint64_t m_n_rider_steps = 0;
     };
 
 // ---------------------------------------------------------------------------------------------

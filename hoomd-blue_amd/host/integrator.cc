@@ -132,6 +132,33 @@ IntegratorTwoStep::IntegratorTwoStep(std::shared_ptr<SystemDefinition> sysdef, S
 IntegratorTwoStep::~IntegratorTwoStep()
     {
     m_pdata->aliasNetForce(nullptr);
+    m_pdata->setStepRiderSource(nullptr);
+    }
+
+// What a force kernel needs to run the second half of time step `timestep - 1` and the first half of `timestep`
+// behind the forces of `timestep` (the integrator's side of hmd_fused_step_args_t; the neighbor list adds the rest).
+bool IntegratorTwoStep::fillStepRider(hmd_fused_step_args_t& a, uint64_t timestep)
+    {
+    if (!m_rider_armed || timestep != m_rider_tstep)
+        return false;
+    auto method = m_methods[0];
+    a.two.d_vel = m_pdata->vel();
+    a.two.d_accel = nullptr;
+    a.two.d_group_members = method->getGroup()->getIndexArray();
+    a.two.group_size = method->getGroup()->getNumMembers();
+    a.two.d_net_force = m_pdata->netForceForIntegration();
+    a.two.deltaT = m_deltaT;
+    a.two.rescale_factor = 1.0;
+    a.one.d_pos = m_pdata->pos();
+    a.one.d_vel = m_pdata->vel();
+    a.one.d_accel = nullptr;
+    a.one.d_image = m_pdata->image();
+    a.one.d_group_members = a.two.d_group_members;
+    a.one.group_size = a.two.group_size;
+    a.one.box = m_pdata->getBox().b;
+    a.one.rescale_factor = 1.0;
+    a.one.deltaT = m_deltaT;
+    return a.one.d_group_members == nullptr && a.one.group_size == m_pdata->getN();
     }
 
 void IntegratorTwoStep::setDeltaT(Scalar dt)
@@ -265,7 +292,12 @@ void IntegratorTwoStep::update(uint64_t timestep)
         if (nve && !nve->canFuse())
             nve = nullptr;
         }
-    if (nve && m_pending_two && m_pending_tstep + 1 == timestep)
+    if (nve && m_step_one_done_for == timestep)
+        {
+        // the previous step's force kernel went on with the second half of that step and the first half of this one
+        m_step_one_done_for = ~0ull;
+        }
+    else if (nve && m_pending_two && m_pending_tstep + 1 == timestep)
         {
         nve->setDeltaT(m_deltaT);
         nve->integrateStepTwoOne(m_pending_tstep);
@@ -282,8 +314,23 @@ void IntegratorTwoStep::update(uint64_t timestep)
         }
     if (m_sysdef->isDomainDecomposed())
         m_sysdef->getCommunicator()->communicate(timestep + 1);
+    // The force kernel of this step may take the second half of the step and the first half of the next one along,
+    // when the run loop has promised that the next update() follows with nothing in between: one method without
+    // thermostat over every particle, one force, no virial, no domain decomposition.
+    m_rider_armed = nve && m_rider_enabled && m_lookahead && m_forces.size() == 1 && !m_sysdef->isDomainDecomposed() && !m_pdata->getFlag(pressure_tensor);
+    m_rider_tstep = timestep + 1;
+    if (m_rider_armed)
+        m_pdata->setStepRiderSource([this](hmd_fused_step_args_t& a, uint64_t t) { return fillStepRider(a, t); });
     computeNetForceGPU(timestep + 1);
-    if (nve)
+    const bool rode = m_rider_armed && m_pdata->getStepRiderDone() == timestep + 1;
+    m_rider_armed = false;
+    if (rode)
+        {
+        m_step_one_done_for = timestep + 1;
+        m_pending_two = false;
+        m_n_rider_steps++;
+        }
+    else if (nve)
         {
         m_pending_two = true;
         m_pending_tstep = timestep;
@@ -310,6 +357,9 @@ ParticleSorter::ParticleSorter(std::shared_ptr<SystemDefinition> sysdef, uint64_
     m_cl->setFlagIndex();
     m_cl->setComputeAdj(false);
     m_cl->setNmaxHeadroom(4);
+    // members of a cell in index order: the new particle order is then a function of the old one, not of the order in
+    // which the binning kernel's atomics were served (one sort of the cell list per reordering)
+    m_cl->setSortCellList(true);
     }
 
 void ParticleSorter::update(uint64_t timestep)
@@ -378,9 +428,12 @@ void System::run(uint64_t nsteps, bool prepare)
             m_integrator->flush(); // the pending half step reads forces in the old particle order
             m_sorter->update(m_cur_tstep);
             }
+        // does the next update follow this one with nothing in between?
+        m_integrator->setLookahead(s + 1 < nsteps && !(m_sorter && m_sorter->isDue(m_cur_tstep + 1)));
         m_integrator->update(m_cur_tstep);
         m_cur_tstep++;
         }
+    m_integrator->setLookahead(false);
     m_integrator->flush();
     hipCheck(hipStreamSynchronize(0), "hipStreamSynchronize");
     m_integrator->checkForceErrors();

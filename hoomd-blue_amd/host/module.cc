@@ -485,6 +485,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
              i.notifyForcesChanged();
              })
         .def("update", &IntegratorTwoStep::update)
+        .def_property("step_rider", &IntegratorTwoStep::getStepRider, &IntegratorTwoStep::setStepRider)
+        .def_property_readonly("num_rider_steps", &IntegratorTwoStep::getNumRiderSteps)
         .def("prepRun", &IntegratorTwoStep::prepRun)
         .def("computeNetForce", &IntegratorTwoStep::computeNetForceGPU)
         .def("computeLinearMomentum", &IntegratorTwoStep::computeLinearMomentum)

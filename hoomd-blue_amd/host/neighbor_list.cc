@@ -171,7 +171,7 @@ void NeighborListGPUBinned::resetStats()
 
 // arguments of the distance check for the current positions; a fresh check number each time, so the
 // device flag never needs clearing
-void NeighborListGPUBinned::fillCheckArgs(hmd_nlist_check_args_t& a)
+void NeighborListGPUBinned::fillCheckArgs(hmd_nlist_check_args_t& a, bool fresh)
     {
     const auto L_g = m_pdata->getGlobalBox().getNearestPlaneDistance();
     std::memset(&a, 0, sizeof(a));
@@ -185,7 +185,7 @@ void NeighborListGPUBinned::fillCheckArgs(hmd_nlist_check_args_t& a)
     a.d_rcut_max = m_d_rcut_max.get();
     a.r_buff = m_r_buff;
     a.ntypes = m_pdata->getNTypes();
-    a.checkn = ++m_checkn;
+    a.checkn = fresh ? ++m_checkn : m_checkn;
     // The flag comes back through pinned memory that the host polls: no stream synchronisation.  Not from
     // the check itself: whoever consumes the check publishes (the predicated force kernel as its first
     // act, or hmd_publish_word), which saves a launch per step.
@@ -201,7 +201,9 @@ bool NeighborListGPUBinned::offerCheck(hmd_nlist_check_args_t& a, uint64_t times
         return false;
     if (timestep < m_last_updated_tstep + m_rebuild_check_delay || m_last_checked_tstep == timestep)
         return false;
-    fillCheckArgs(a);
+    // (offered twice for one time step when the kernel that carried the check was switched off and is launched again
+    // after the rebuild: the same check number then)
+    fillCheckArgs(a, m_prelaunched_tstep != timestep);
     m_prelaunched_tstep = timestep;
     return true;
     }
@@ -217,6 +219,30 @@ void NeighborListGPUBinned::offerFusedPass(hmd_fused_step_args_t& a, uint64_t ti
         a.d_cpos = m_cpos.get();
         m_cpos_tstep = timestep;
         }
+    }
+
+bool NeighborListGPUBinned::offerStepRider(hmd_fused_step_args_t& a, uint64_t timestep)
+    {
+    if (!m_tiles_active || m_force_update || !m_has_been_updated_once || m_slot_of.size() < m_pdata->getN() || m_pdata->getNGhosts() != 0)
+        return false;
+    const bool had = m_prelaunched_tstep == timestep;
+    if (!offerCheck(a.check, timestep))
+        {
+        std::memset(&a.check, 0, sizeof(a.check));
+        if (had)
+            m_prelaunched_tstep = ~0ull;
+        }
+    if (m_cpos_alt.size() != m_cpos.size())
+        m_cpos_alt.resize(m_cpos.size(), false);
+    a.d_slot_of = m_slot_of.get();
+    a.d_cpos = m_cpos_alt.get();
+    return true;
+    }
+
+void NeighborListGPUBinned::commitStepRider(uint64_t timestep)
+    {
+    m_cpos.swap(m_cpos_alt);
+    m_cpos_tstep = timestep;
     }
 
 // hoomd/md/NeighborListGPU.cc:29-101
@@ -295,18 +321,20 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
             }
         }
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_h_words.get() + 16);
+    // (the consumer's kernel may carry the next time step's check and take a new number for it)
+    const unsigned int checkn = m_checkn;
     if (!m_sysdef->isDomainDecomposed())
         {
         unsigned long long* d_pub = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
         // only on the consumer's own path (compute): nothing else touches the particles before the forces
-        if (!(m_speculate && m_in_compute && m_speculate(timestep, m_flag.get(), m_checkn, d_pub, m_checkn)))
-            abiCheck(hmd_publish_word(m_flag.get(), d_pub, m_checkn, nullptr), "hmd_publish_word");
+        if (!(m_speculate && m_in_compute && m_speculate(timestep, m_flag.get(), checkn, d_pub, checkn)))
+            abiCheck(hmd_publish_word(m_flag.get(), d_pub, checkn, nullptr), "hmd_publish_word");
         }
     else
-        abiCheck(hmd_publish_word(m_flag.get(), reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16), m_checkn, nullptr),
+        abiCheck(hmd_publish_word(m_flag.get(), reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16), checkn, nullptr),
                  "hmd_publish_word");
-    const unsigned long long v = pollStampedWord(h, m_checkn, "distance check");
-    bool result = ((unsigned int)v == m_checkn);
+    const unsigned long long v = pollStampedWord(h, checkn, "distance check");
+    bool result = ((unsigned int)v == checkn);
     if (m_sysdef->isDomainDecomposed())
         result = m_sysdef->getCommunicator()->anyRank(result);
     return result;

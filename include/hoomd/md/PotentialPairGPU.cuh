@@ -32,6 +32,7 @@ struct pair_args_t
     const hmd_tile_geom_t* tile_geom;    //!< non-null: use the tile kernel with these rows
     const unsigned short* d_tile_nlist;
     hipStream_t stream;
+    const hmd_fused_step_args_t* step;   //!< non-null (tile kernel only): the integration pass rides on the kernel
     };
 
 // hipSuccess, or hipErrorInvalidValue with the reason in hmd_last_error()
@@ -55,7 +56,7 @@ template<class evaluator> hipError_t gpu_compute_pair_forces(const pair_args_t& 
     static_assert(std::is_trivially_copyable<typename evaluator::param_type>::value || __is_trivially_copyable(typename evaluator::param_type),
                   "param_type is copied into LDS byte by byte");
     const int rc = pair_args.tile_geom
-                       ? hmd::launch_pair_forces_tiles<evaluator>(&pair_args.args, pair_args.tile_geom, pair_args.d_tile_nlist, d_params, pair_args.stream)
+                       ? hmd::launch_pair_forces_tiles<evaluator>(&pair_args.args, pair_args.tile_geom, pair_args.d_tile_nlist, d_params, pair_args.stream, pair_args.step)
                        : hmd::launch_pair_forces<evaluator>(&pair_args.args, d_params, pair_args.stream, "pair");
     return rc == HMD_OK ? hipSuccess : hipErrorInvalidValue;
     }

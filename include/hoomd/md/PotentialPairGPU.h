@@ -59,6 +59,7 @@ template<class evaluator> class PotentialPairGPU : public PotentialPair<evaluato
         {
         // The speculation hook may already have queued this step's kernel: from inside compute() below, or, under
         // domain decomposition, from the communicator's look at the rebuild decision before this call.
+        m_force_tstep = timestep;
         this->m_nlist->compute(timestep);
         if (this->m_nlist->getStorageMode() == NeighborList::half)
             throw std::runtime_error("PotentialPairGPU cannot handle a half neighborlist");
@@ -66,9 +67,23 @@ template<class evaluator> class PotentialPairGPU : public PotentialPair<evaluato
         const bool queued = m_spec_tstep == timestep && this->m_nlist->getLastBuildTimestep() != timestep;
         m_spec_tstep = ~0ull;
         if (!queued)
+            {
+            m_rider_tstep = ~0ull; // (a switched-off launch has not run its pass either)
             launchKernel(nullptr, 0);
+            }
+        if (m_rider_tstep == timestep)
+            {
+            // the kernel that stands carried the integrator's half steps: the positions of timestep + 1 exist
+            this->m_nlist->commitStepRider(timestep + 1);
+            this->m_pdata->notifyStepRiderDone(timestep);
+            }
+        m_rider_tstep = ~0ull;
+        m_force_tstep = ~0ull;
         this->computeTailCorrection();
         }
+    //! the time step of the force computation in progress (launchKernel is also called from the neighbor list's hooks)
+    uint64_t m_force_tstep = ~0ull;
+    uint64_t m_rider_tstep = ~0ull; // time step whose queued kernel carries the integrator's half steps
     //! part: 0 every particle; 1 the blocks of tiles that see no ghosts; 2 the other blocks
     bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0,
                       unsigned int part = 0);
@@ -156,14 +171,33 @@ bool PotentialPairGPU<evaluator>::launchKernel(const unsigned int* d_skip_flag, 
         }
     if (tiles && part != 1) // (the interior blocks read owned particles only, whose copies are current)
         nlist->refreshTilePositions();
-    ScopedKernelTimer t(part == 1 ? "pair_force_interior" : "pair_force");
     hmd_tile_geom_t g;
+    hmd_fused_step_args_t step;
     if (tiles)
         {
         g = nlist->getTileGeom();
         pa.tile_geom = &g;
         pa.d_tile_nlist = nlist->getTileNlist().get();
+        // The integrator may offer its half steps around this force computation to the kernel (one NVE method, every
+        // particle, the next time step certain to follow): taken when the whole grid is launched at once, without
+        // virials, by the tile kernel, in the case the kernel carries (hmd_pair_forces_tiles_step_supported).
+        const auto& source = pdata->getStepRiderSource();
+        if (source && part == 0 && !a.compute_virial && m_force_tstep != ~0ull && a.N != 0)
+            {
+            std::memset(&step, 0, sizeof(step));
+            if (source(step, m_force_tstep) && nlist->offerStepRider(step, m_force_tstep + 1))
+                {
+                if (hmd_pair_forces_tiles_step_supported(&a, &step) == HMD_OK)
+                    {
+                    pa.step = &step;
+                    m_rider_tstep = m_force_tstep;
+                    }
+                else
+                    nlist->withdrawStepRider(m_force_tstep + 1);
+                }
+            }
         }
+    ScopedKernelTimer t(part == 1 ? "pair_force_interior" : (pa.step ? "pair_force_step" : "pair_force"));
     if (kernel::gpu_compute_pair_forces<evaluator>(pa, m_d_params.get()) != hipSuccess)
         throw std::runtime_error(std::string("gpu_compute_pair_forces<") + std::string(evaluator::getName()) + ">: " + hmd_last_error());
     return a.N != 0; // the drivers launch nothing for an empty system

@@ -933,6 +933,30 @@ int hmd_compute_pair_forces_lj_tiles(const hmd_pair_args_t* args, const hmd_tile
 int hmd_compute_pair_forces_example_tiles(const hmd_pair_args_t* args, const hmd_tile_geom_t* geom,
                                           const unsigned short* d_tile_nlist, const hmd_example_params_t* d_params, void* stream);
 
+/* hmd_compute_pair_forces_lj_tiles with the pass of hmd_nve_step_two_one_check riding on it: the lane that finishes
+   a particle's force (gpu_compute_pair_forces, hoomd/md/PotentialPairGPU.cuh:140-404) goes on with the second half of
+   the time step (hoomd/md/TwoStepConstantVolumeGPU.cu:215-260), the first half of the next one (:102-155), the distance
+   check of the new position (hoomd/md/NeighborListGPU.cu:42-84) and the slot-ordered copy, so a time step of an NVE
+   run with one pair force is ONE kernel.  Forces (args->d_force) are stored as always; positions, velocities, images,
+   the check's result and step->d_cpos come out bit-identical to hmd_compute_pair_forces_lj_tiles followed by
+   hmd_nve_step_two_one_check with two.d_net_force = args->d_force.  Requirements: no virial, the whole grid of blocks
+   (block_window_mode 0), the group is every particle (d_group_members NULL, group_size == args->N), no displacement
+   limit, one.d_vel == two.d_vel, and step->d_cpos / d_slot_of set with d_cpos a buffer OTHER than geom->d_cpos (the
+   kernel stages from geom->d_cpos while it writes the new positions; the caller swaps the two buffers afterwards).
+   two.d_net_force and one.d_accel are not read; two.d_accel must be NULL (the accelerations are not stored).  The
+   pass rides only in the case of a plain NVE run: orthorhombic box periodic in all directions and unchanged since the
+   neighbor list was built (check.box == one.box, lambda == 1), rescale factors 1, one time step length;
+   hmd_pair_forces_tiles_step_supported returns HMD_OK when it can ride and HMD_ERR_UNSUPPORTED (reason in
+   hmd_last_error()) when the caller has to run the two entry points one after the other.  A launch that
+   args->d_skip_flag switches off leaves everything untouched. */
+int hmd_pair_forces_tiles_step_supported(const hmd_pair_args_t* args, const hmd_fused_step_args_t* step);
+int hmd_compute_pair_forces_lj_tiles_step(const hmd_pair_args_t* args,
+                                          const hmd_tile_geom_t* geom,
+                                          const unsigned short* d_tile_nlist,
+                                          const hmd_lj_params_t* d_params,
+                                          const hmd_fused_step_args_t* step,
+                                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,6 @@ timeout -k 10 200 python tests/dbg/pft_bench.py --make-liquid 2>&1 | tail -1 || 
 for rep in 1 2; do
   for v in "$@"; do
     if [ "$v" = base ]; then unset HOOMD_AMD_LIB; else export HOOMD_AMD_LIB=$V/$v/libhoomd_amd.so; fi
-    echo -n "$v: "; timeout -k 10 100 python tests/dbg/pft_bench.py 2>&1 | tail -1 || exit 1
+    echo -n "$v: "; timeout -k 10 100 python tests/dbg/pft_bench.py $AB_ARGS 2>&1 | tail -${AB_LINES:-1} || exit 1
   done
 done

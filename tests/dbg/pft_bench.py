@@ -61,6 +61,29 @@ def timeit(f, reps=30):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 print("tile force us %.1f" % timeit(lambda: A.check(fn(C.byref(pa), C.byref(gfast), K.ptr(tl["tiles"]), K.ptr(prm_t), None))), "fsum", float(force[:, :3].abs().sum()))
+if "--step" in sys.argv:
+    # the same launch with the integration pass riding on it (positions and velocities move on; the forces, computed
+    # from the slot-ordered copy that is not swapped here, stay the same)
+    vel = torch.cat([torch.randn((N, 3), dtype=torch.float64, device="cuda"), torch.ones((N, 1), dtype=torch.float64, device="cuda")], 1).contiguous()
+    image = torch.zeros((N, 3), dtype=torch.int32, device="cuda")
+    cpos_new = torch.zeros_like(cpos)
+    res = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rcm = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+    pos_w = pos_t.clone()
+    st = A.FusedStepArgs()
+    st.two.d_vel, st.two.d_net_force, st.two.group_size, st.two.deltaT, st.two.rescale_factor = K.ptr(vel), K.ptr(force), N, 1e-5, 1.0
+    st.one.d_pos, st.one.d_vel, st.one.d_image = K.ptr(pos_w), K.ptr(vel), K.ptr(image)
+    st.one.group_size, st.one.box, st.one.rescale_factor, st.one.deltaT = N, gbox, 1.0, 1e-5
+    c = st.check
+    c.d_result, c.d_last_pos, c.d_pos, c.N, c.box = K.ptr(res), K.ptr(tl["last_pos"]), K.ptr(pos_w), N, gbox
+    c.d_rcut_max, c.r_buff, c.ntypes, c.lambda_min, c.lam, c.checkn = K.ptr(rcm), 0.4, 1, 1.0, K._s3((1.0, 1.0, 1.0)), 3
+    st.d_slot_of, st.d_cpos = K.ptr(tl["slot_of"]), K.ptr(cpos_new)
+    fs = A.lib.hmd_compute_pair_forces_lj_tiles_step
+    print("tile force + integration pass us %.1f" % timeit(lambda: A.check(fs(C.byref(pa), C.byref(gfast), K.ptr(tl["tiles"]), K.ptr(prm_t), C.byref(st), None))),
+          "flag", int(res.item()))
+    a2 = A.FusedStepArgs.from_buffer_copy(st)
+    a2.d_cpos = K.ptr(cpos_new)
+    print("integration pass alone us %.1f" % timeit(lambda: A.check(A.lib.hmd_nve_step_two_one_check(C.byref(a2), None))))
 if "--build" in sys.argv:
     def build():
         K.nlist_tiles(pos_t, N, gbox, [[2.5]], 0.4, cl, adj)

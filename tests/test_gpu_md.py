@@ -161,6 +161,33 @@ def test_short_trajectory_and_rebuild_cadence_match_oracle(hoomd):
     assert sim.timestep == 60
 
 
+@pytest.mark.parametrize("sorter", [False, True])
+def test_half_steps_inside_the_force_kernel_change_no_bit(hoomd, sorter):
+    """An NVE run with one pair force takes its half steps inside the force kernel (one kernel per time step); with the
+    switch off the integration pass runs as a kernel of its own.  Same forces, same arithmetic: the trajectories agree
+    bit for bit, through rebuilds, sorts and runs cut into pieces, and so do the rebuild statistics."""
+    snap = jittered_lattice_snapshot(hoomd, 18, jitter=0.05, seed=12)
+    out = []
+    for rider in (True, False):
+        sim, cell, lj, _ = make_sim(hoomd, snap, sorter=sorter)
+        cell.deterministic = True  # (the order of a cell's members, and with it the order of the sums, is the same in both runs)
+        if sorter:
+            sim.operations.tuners[0].trigger = 7
+        sim.run(0)
+        sim.operations.integrator._cpp_obj.step_rider = rider
+        sim.run(33)
+        sim.run(1)
+        sim.run(26)
+        s = sim.state.get_snapshot()
+        n_ride = sim.operations.integrator._cpp_obj.num_rider_steps
+        assert (n_ride > 30) if rider else (n_ride == 0)
+        out.append((s.particles.position.copy(), s.particles.velocity.copy(), s.particles.image.copy(), lj.forces.copy(), lj.energies.copy(),
+                    cell.num_builds, cell.shortest_rebuild, s.particles.acceleration.copy()))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    assert out[0][5] >= 6  # rebuilds happened
+
+
 def test_nve_energy_drift_not_worse_than_cpu_path(hoomd):
     snap = jittered_lattice_snapshot(hoomd, 16, jitter=0.05, kT=1.0)
     N = snap.particles.N

@@ -239,3 +239,75 @@ def test_tile_forces_by_block_window(K, A, fast, wlo, whi):
         K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], window=(1, (0, 0, 0), (nb[0], 0, 0)))
     with pytest.raises(A.KernelError, match="block_window_mode"):
         K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, [[6.25]], window=(3, (0, 0, 0), (0, 0, 0)))
+
+
+@pytest.mark.parametrize("n,ntypes,dt,edges", [(12, 1, 0.005, False), (12, 1, 0.005, True), (16, 1, 0.04, True), (13, 2, 0.005, True)])
+def test_tile_force_kernel_carries_the_integration_pass(K, A, n, ntypes, dt, edges):
+    """hmd_compute_pair_forces_lj_tiles_step against the two entry points it joins: forces, positions (with particles
+    wrapped through the box faces), velocities, images, the slot-ordered copy and the distance check, bit for bit; and a
+    launch that its predicate switches off leaves everything alone."""
+    xyz, typ, L = liquid(n, ntypes=ntypes, seed=21)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    rng = np.random.default_rng(6)
+    pos = orc.pack_pos(xyz, typ)
+    # some particles right at the faces, moving outwards (they overlap others: large forces, the list goes stale)
+    edge = rng.permutation(N)[: 40 if edges else 0]
+    axis = rng.integers(0, 3, len(edge))
+    side = rng.choice([-1.0, 1.0], len(edge))
+    pos[edge, axis] = side * (L / 2 - 1e-5)
+    pos_t = torch.from_numpy(pos).cuda()
+    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, 2.2]]
+    tl, cl, dim = tile_nlist(K, A, pos_t, N, gbox, obox, r_cut, 0.4)
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1)) if ntypes == 2 else np.ones((N, 1))], 1)
+    vel[edge, axis] = side * 1.5
+    image = rng.integers(-2, 3, (N, 3)).astype(np.int32)
+    P = [orc.lj_params(1.0, 1.0)] if ntypes == 1 else [orc.lj_params(1.0, 1.0), orc.lj_params(1.5, 0.8), orc.lj_params(1.5, 0.8), orc.lj_params(0.5, 0.88)]
+    rcsq = (np.asarray(r_cut) ** 2).tolist()
+    rcut_max = [max(r) for r in r_cut]
+    # the two entry points one after the other
+    p1, v1, i1 = pos_t.clone(), torch.from_numpy(vel).cuda(), torch.from_numpy(image).cuda()
+    F1, _ = K.pair_forces_tiles("lj", p1, N, gbox, tl, P, rcsq, compute_virial=False, fast=True)
+    cpos1 = K.tile_refresh(p1, tl)
+    flag1, _ = K.fused_step(p1, v1, None, i1, F1, gbox, dt, last_pos=tl["last_pos"], rcut_max=rcut_max, r_buff=0.4, checkn=7, slot_of=tl["slot_of"], cpos=cpos1)
+    assert not edges or (i1.cpu().numpy() != image).any()  # particles did cross the faces
+    # the joined kernel
+    p2, v2, i2 = pos_t.clone(), torch.from_numpy(vel).cuda(), torch.from_numpy(image).cuda()
+    F2, cpos2, flag2 = K.pair_forces_tiles_step(p2, v2, i2, N, gbox, tl, P, rcsq, dt, last_pos=tl["last_pos"], rcut_max=rcut_max, r_buff=0.4, checkn=7)
+    assert np.array_equal(F2.cpu().numpy()[:N], F1.cpu().numpy()[:N])
+    assert np.array_equal(p2.cpu().numpy(), p1.cpu().numpy()) and np.array_equal(v2.cpu().numpy(), v1.cpu().numpy())
+    assert np.array_equal(i2.cpu().numpy(), i1.cpu().numpy())
+    slots = tl["slot_of"].cpu().numpy().view(np.uint32)[:N]
+    assert np.array_equal(cpos2.cpu().numpy()[slots], cpos1.cpu().numpy()[slots])
+    assert flag2 == flag1
+    # switched off: nothing moves
+    p3, v3, i3 = pos_t.clone(), torch.from_numpy(vel).cuda(), torch.from_numpy(image).cuda()
+    word = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+    F3, cpos3, flag3 = K.pair_forces_tiles_step(p3, v3, i3, N, gbox, tl, P, rcsq, dt, last_pos=tl["last_pos"], rcut_max=rcut_max, r_buff=0.4, checkn=7,
+                                                skip=(word, 5))
+    assert np.array_equal(p3.cpu().numpy(), pos) and np.array_equal(v3.cpu().numpy(), vel) and flag3 == 0
+    assert np.isnan(F3.cpu().numpy()).all() and np.isnan(cpos3.cpu().numpy()).all()
+
+
+def test_step_pass_is_declined_outside_its_case(K, A):
+    """A triclinic box, a rescaling factor or a displacement limit: hmd_pair_forces_tiles_step_supported says no (and names
+    the reason) instead of running something else than the two entry points would."""
+    import ctypes as C
+    a, s = A.PairArgs(), A.FusedStepArgs()
+    gbox = A.Box.from_L(10.0, 10.0, 10.0)
+    a.N = 100
+    dummy = torch.zeros(8, dtype=torch.float64, device="cuda")
+    s.one.d_pos = s.one.d_vel = s.two.d_vel = s.one.d_image = K.ptr(dummy)
+    s.one.group_size = s.two.group_size = 100
+    s.one.rescale_factor = s.two.rescale_factor = 1.0
+    s.one.deltaT = s.two.deltaT = 0.005
+    s.one.box = gbox
+    assert A.lib.hmd_pair_forces_tiles_step_supported(C.byref(a), C.byref(s)) == 0
+    s.one.rescale_factor = 0.99
+    assert A.lib.hmd_pair_forces_tiles_step_supported(C.byref(a), C.byref(s)) != 0 and b"rescal" in A.lib.hmd_last_error()
+    s.one.rescale_factor = 1.0
+    s.one.box = A.Box.from_L(10.0, 10.0, 10.0, 0.1, 0.0, 0.0)
+    assert A.lib.hmd_pair_forces_tiles_step_supported(C.byref(a), C.byref(s)) != 0 and b"orthorhombic" in A.lib.hmd_last_error()
+    s.one.box = gbox
+    a.compute_virial = 1
+    assert A.lib.hmd_pair_forces_tiles_step_supported(C.byref(a), C.byref(s)) != 0
