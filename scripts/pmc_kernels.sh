@@ -22,7 +22,7 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in ("p1", "p2"):
     for f in glob.glob(f"{out}/{p}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:100]
             vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in vals.items():

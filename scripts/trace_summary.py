@@ -23,7 +23,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.split("(")[0][:80]
+    return n.split("(")[0][:100]
 
 
 pf = [r for r in rows if "pair_force" in r["Kernel_Name"]]
