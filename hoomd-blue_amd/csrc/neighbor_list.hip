@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                             ct[c] = tb.x;
                             cb[c] = tb.y;
                             }
+                        if (TILE && !SINGLE_TYPE)
+                            cl[c] |= ct[c] << hmd::TL_TYPE_SHIFT; // rows for several types carry the candidate's type
                         }
                     }
                 }
@@ -726,6 +728,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         z32 = (float)(HMD_ADD(vzw[q].x, s_shift[3 * lo + 2]) - Oz);
                         const unsigned int k = pbase + c * 64 + lane;
                         co[c] = TILE ? hmd::tile_slot(s_tileoff[lo] + (k - s_excl[lo])) : hmd_double_as_uint(vzw[q].y);
+                        if (TILE && TWO)
+                            co[c] |= (vty[q] & 1u) << hmd::TL_TYPE_SHIFT; // rows for several types carry the candidate's type
                         }
                     if (c & 1)
                         {

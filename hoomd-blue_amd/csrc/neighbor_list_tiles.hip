@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
     __syncthreads();
     const unsigned int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const unsigned int grp0 = a.geom.d_block_group[vb];
+    const unsigned int slot_mask = a.ntypes > 1 ? TL_SLOT_MASK : 0xffffu; // (rows for several types: type in the top bits)
     unsigned int hfirst = 0; // number of the home cell's first member among the block's home particles
     for (unsigned int hc = 0; hc < (unsigned int)TL_NH; hc++)
         {
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
             const unsigned int n = min(a.d_n_neigh[i], a.geom.row_pieces * TL_PIECE);
             const size_t head = a.d_head_list[i];
             for (unsigned int k = lane; k < n; k += 64)
-                a.d_nlist[head + k] = tidx[tile_unslot(trow[((k & ~15u) << 4) | (k & 15u)])];
+                a.d_nlist[head + k] = tidx[tile_unslot((unsigned int)trow[((k & ~15u) << 4) | (k & 15u)] & slot_mask)];
             }
         hfirst += n_cell;
         }
@@ -88,8 +89,16 @@ extern "C" int hmd_nlist_tiles_supported(const hmd_index3d_t* ci, const hmd_box_
         HMD_REQUIRE(!box->periodic[d] || dim[d] >= 3, HMD_ERR_UNSUPPORTED,
                     "tile path needs at least 3 cells along every periodic direction");
         }
-    HMD_REQUIRE(ntypes >= 1 && ntypes <= 256, HMD_ERR_UNSUPPORTED, "tile path stores type ids in one byte");
-    const size_t cap = (size_t)hmd::TL_RC * cell_Nmax;
+    HMD_REQUIRE(ntypes >= 1 && ntypes <= hmd::TL_MAX_ROW_TYPES, HMD_ERR_UNSUPPORTED, "tile path: rows carry type ids in three bits (at most 8 types)");
+    size_t cap = (size_t)hmd::TL_RC * cell_Nmax;
+    if (ntypes > 1)
+        {
+        // typed rows address 8192 tile slots: the largest capacity whose dummy candidate still has one
+        size_t typed_cap = 0;
+        while (hmd::tile_slot((unsigned int)(typed_cap + 1)) <= hmd::TL_SLOT_MASK)
+            typed_cap++;
+        cap = std::min(cap, typed_cap);
+        }
     HMD_REQUIRE(cap >= 1 && hmd::tile_doubles((unsigned int)std::min<size_t>(cap, 1u << 20)) <= 65536 && build_lds_bytes((unsigned int)cap, ntypes) <= hmd::TL_MAX_LDS, HMD_ERR_UNSUPPORTED,
                 "tile path: 64 cells of this occupancy do not fit the LDS tile");
     *capacity_out = (unsigned int)cap;

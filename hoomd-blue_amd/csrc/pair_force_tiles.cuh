@@ -27,6 +27,7 @@ struct pft_home_t
     unsigned int nn_lh; // low half: number of neighbors; high half: tile slot of the particle itself
     };
 static_assert(sizeof(pft_home_t) == 8, "LDS budget");
+// (with several particle types lh carries the particle's type above the slot, like a row entry: tile.cuh, TL_TYPE_SHIFT)
 __device__ __forceinline__ pft_home_t pft_home(unsigned int idx, unsigned int nn, unsigned int lh)
     {
     pft_home_t e = {idx, min(nn, 0xffffu) | (lh << 16)};
@@ -356,7 +357,6 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
     double* s_rcutsq = reinterpret_cast<double*>(s_dyn + (size_t)tile_len * 8 + PFT_TABLES + pft_home_bytes(g.cli.w));
     double* s_ronsq = s_rcutsq + (SINGLE_TYPE ? 0 : np);
     param_t* s_params = reinterpret_cast<param_t*>(s_ronsq + (SINGLE_TYPE ? 0 : np));
-    unsigned char* ttype = reinterpret_cast<unsigned char*>(s_params + (SINGLE_TYPE ? 0 : np));
 
     // ---- which block of the grid: all of them in launch order, or those inside / outside a window ----
     const unsigned int nbx = lp.nbx, nby = lp.nby;
@@ -537,8 +537,6 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             txyz[v] = x;
             txyz[v + 32] = y;
             txyz[v + 64] = z;
-            if (!SINGLE_TYPE)
-                ttype[v] = (unsigned char)pp.t;
         };
         if (k16 < size)
             place(pA[u], k16);
@@ -552,9 +550,9 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             if (home_cell)
                 hfirst = T.hcum[((u - 1) * TB_Y + (wave - 1)) * TB_X + (rx - 1)];
             if (home_cell && k16 < size)
-                s_home[hfirst + k16] = pft_home(mA[u - 1].x, mA[u - 1].y, tile_slot(first + k16));
+                s_home[hfirst + k16] = pft_home(mA[u - 1].x, mA[u - 1].y, tile_slot(first + k16) | (SINGLE_TYPE ? 0u : pA[u].t << TL_TYPE_SHIFT));
             if (home_cell && k16 + 16u < size)
-                s_home[hfirst + k16 + 16u] = pft_home(mB[u - 1].x, mB[u - 1].y, tile_slot(first + k16 + 16u));
+                s_home[hfirst + k16 + 16u] = pft_home(mB[u - 1].x, mB[u - 1].y, tile_slot(first + k16 + 16u) | (SINGLE_TYPE ? 0u : pB[u].t << TL_TYPE_SHIFT));
             }
         // cells with more than 32 members (uncommon): the rest, one dependent load per trip
         if (__builtin_amdgcn_readfirstlane(__ballot(size > 32u) != 0))
@@ -562,11 +560,12 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             const unsigned int base = (unsigned int)((az[u].c * dimy + ay.c) * dimx + ax.c) * cellNmax;
             for (unsigned int k = k16 + 32u; k < size; k += 16u)
                 {
-                place(pft_ld_pos<!SINGLE_TYPE>(g.d_cpos + base + k), k);
+                const pft_pos pk = pft_ld_pos<!SINGLE_TYPE>(g.d_cpos + base + k);
+                place(pk, k);
                 if (home_cell)
                     {
                     const uint2 m = *reinterpret_cast<const uint2*>(g.d_slot_meta + base + k);
-                    s_home[hfirst + k] = pft_home(m.x, m.y, tile_slot(first + k));
+                    s_home[hfirst + k] = pft_home(m.x, m.y, tile_slot(first + k) | (SINGLE_TYPE ? 0u : pk.t << TL_TYPE_SHIFT));
                     }
                 }
             }
@@ -578,8 +577,6 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
         txyz[v] = 1e30;
         txyz[v + 32] = 1e30;
         txyz[v + 64] = 1e30;
-        if (!SINGLE_TYPE)
-            ttype[v] = 0;
         }
     __syncthreads();
 
@@ -610,11 +607,11 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
     {
         const unsigned int h = grp * TL_GROUP + gl;
         const pft_home_t e = s_home[min(h, H)]; // s_home[H] is an empty entry
-        const unsigned int lh = e.nn_lh >> 16;
+        const unsigned int lh = SINGLE_TYPE ? e.nn_lh >> 16 : (e.nn_lh >> 16) & TL_SLOT_MASK;
         const unsigned int nn = min(e.nn_lh & 0xffffu, P * TL_PIECE);
         pf_accum acc;
         const double xi = txyz[lh], yi = txyz[lh + 32], zi = txyz[lh + 64];
-        const unsigned int ti = SINGLE_TYPE ? 0u : (unsigned int)ttype[lh];
+        const unsigned int ti = SINGLE_TYPE ? 0u : e.nn_lh >> (16u + TL_TYPE_SHIFT);
         // Two particle types: the two parameter sets a pair with this home particle can have sit in registers, chosen
         // per neighbor by its type byte -- one LDS read per pair besides the coordinates instead of four in a
         // dependent chain (type, then the table row), which made the binary mixture LDS-bound.
@@ -636,13 +633,28 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             {
             double x[4], y[4], z[4];
             unsigned int j[4];
+            unsigned int t[SINGLE_TYPE ? 1 : 4]; // several particle types: the neighbors' types, from the top bits of the entries
             };
         auto read_quad = [&](uint2 w, quad& c)
         {
-            c.j[0] = pft_slot_bytes<0>(w.x, three);
-            c.j[1] = pft_slot_bytes<1>(w.x, three);
-            c.j[2] = pft_slot_bytes<0>(w.y, three);
-            c.j[3] = pft_slot_bytes<1>(w.y, three);
+            if (SINGLE_TYPE)
+                {
+                c.j[0] = pft_slot_bytes<0>(w.x, three);
+                c.j[1] = pft_slot_bytes<1>(w.x, three);
+                c.j[2] = pft_slot_bytes<0>(w.y, three);
+                c.j[3] = pft_slot_bytes<1>(w.y, three);
+                }
+            else
+                {
+                c.j[0] = __builtin_amdgcn_ubfe(w.x, 0u, TL_TYPE_SHIFT) << 3;
+                c.j[1] = __builtin_amdgcn_ubfe(w.x, 16u, TL_TYPE_SHIFT) << 3;
+                c.j[2] = __builtin_amdgcn_ubfe(w.y, 0u, TL_TYPE_SHIFT) << 3;
+                c.j[3] = __builtin_amdgcn_ubfe(w.y, 16u, TL_TYPE_SHIFT) << 3;
+                c.t[0 % (SINGLE_TYPE ? 1 : 4)] = __builtin_amdgcn_ubfe(w.x, TL_TYPE_SHIFT, 16u - TL_TYPE_SHIFT);
+                c.t[1 % (SINGLE_TYPE ? 1 : 4)] = w.x >> (16u + TL_TYPE_SHIFT);
+                c.t[2 % (SINGLE_TYPE ? 1 : 4)] = __builtin_amdgcn_ubfe(w.y, TL_TYPE_SHIFT, 16u - TL_TYPE_SHIFT);
+                c.t[3 % (SINGLE_TYPE ? 1 : 4)] = w.y >> (16u + TL_TYPE_SHIFT);
+                }
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 {
@@ -681,7 +693,7 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                         }
                     else
                         {
-                        const bool second = ttype[c.j[m] >> 3] != 0;
+                        const bool second = c.t[m % (SINGLE_TYPE ? 1 : 4)] != 0u;
                         rc[m] = second ? rc2[1] : rc2[0];
                         pp[m] = second ? &prm2[1] : &prm2[0];
                         }
@@ -702,7 +714,7 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                     }
                 else if (TWO_TYPES)
                     {
-                    const bool second = ttype[c.j[m] >> 3] != 0;
+                    const bool second = c.t[m % (SINGLE_TYPE ? 1 : 4)] != 0u;
                     rcutsq = second ? rc2[1] : rc2[0];
                     if (SHIFT == 2)
                         ronsq = second ? ro2[1] : ro2[0];
@@ -712,7 +724,7 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                     }
                 else
                     {
-                    const unsigned int tp = (unsigned int)ttype[c.j[m] >> 3] * a.ntypes + ti;
+                    const unsigned int tp = c.t[m % (SINGLE_TYPE ? 1 : 4)] * a.ntypes + ti;
                     rcutsq = s_rcutsq[tp];
                     if (SHIFT == 2)
                         ronsq = s_ronsq[tp];
@@ -839,7 +851,7 @@ template<class Ev> static inline size_t pft_lds_bytes(unsigned int cap, unsigned
     {
     size_t b = (size_t)tile_doubles(cap) * 8 + PFT_TABLES + pft_home_bytes(cell_Nmax);
     if (ntypes > 1)
-        b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type)) + tile_doubles(cap);
+        b += (size_t)ntypes * ntypes * (16 + sizeof(typename Ev::param_type));
     return (b + 15) / 16 * 16;
     }
 

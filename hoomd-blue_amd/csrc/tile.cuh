@@ -61,6 +61,11 @@ __host__ __device__ constexpr size_t tile_group_entries(unsigned int P)
     }
 // pieces past the last group that the force kernel's prefetch may read
 constexpr unsigned int TL_SLACK_GROUPS = 2;
+// Rows built for more than one particle type carry the candidate's type in the top bits of the 16-bit entry (slot in
+// the low 13 bits): the force kernel then needs no table of types beside the tile, which is 6 KB of LDS at a capacity
+// of 2000 candidates and decides how many workgroups a compute unit holds.  Such rows need tile_slot(capacity) < 8192
+// and at most eight types (hmd_nlist_tiles_supported says so).
+constexpr unsigned int TL_TYPE_SHIFT = 13, TL_SLOT_MASK = (1u << TL_TYPE_SHIFT) - 1u, TL_MAX_ROW_TYPES = 1u << (16u - TL_TYPE_SHIFT);
 
 // region cell number of region coordinates, and of home cell hc = (hz*TB_Y + hy)*TB_X + hx
 __host__ __device__ constexpr int tile_rc(int rx, int ry, int rz)

@@ -243,7 +243,7 @@ class NlistTilesArgs(C.Structure):
 
 class TilesToRowsArgs(C.Structure):
     _fields_ = [("geom", TileGeom), ("d_tile_nlist", vp), ("d_n_neigh", vp), ("d_head_list", vp), ("d_nlist", vp), ("N", u32),
-                ("box", Box)]
+                ("box", Box), ("ntypes", u32)]
 
 
 # every symbol the header declares, with its signature

@@ -248,7 +248,7 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None, exclusions=N
         check(_abi.lib.hmd_tile_slots(C.byref(geom), ptr(slot_of), _stream(pos)), "hmd_tile_slots")
         # geom points into the cell list's tensors: keep them alive with the result
         return dict(slot_meta=slot_meta, slot_of=slot_of, tiles=tiles, n_neigh=n_neigh, head=head, last_pos=last_pos, Nmax=Nmax_t, n_builds=n_builds, geom=geom, args=a,
-                    cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow, block_group=block_group, nlist_size=total)
+                    cell_list=cl, adj=adj, r_cut=r_cut_t, overflow=overflow, block_group=block_group, nlist_size=total, ntypes=nt)
 
 
 def tiles_to_rows(tl, N, box):
@@ -257,6 +257,7 @@ def tiles_to_rows(tl, N, box):
     a = _abi.TilesToRowsArgs()
     a.geom = tl["geom"]
     a.d_tile_nlist, a.d_n_neigh, a.d_head_list, a.d_nlist, a.N, a.box = ptr(tl["tiles"]), ptr(tl["n_neigh"]), ptr(tl["head"]), ptr(nlist), N, box
+    a.ntypes = tl["ntypes"]
     check(_abi.lib.hmd_nlist_tiles_to_rows(C.byref(a), _stream(nlist)), "hmd_nlist_tiles_to_rows")
     return nlist
 

@@ -686,6 +686,7 @@ void NeighborListGPUBinned::ensureRows()
     a.d_nlist = m_nlist.get();
     a.N = m_pdata->getN();
     a.box = m_pdata->getBox().b;
+    a.ntypes = m_pdata->getNTypes();
     abiCheck(hmd_nlist_tiles_to_rows(&a, nullptr), "hmd_nlist_tiles_to_rows");
     m_rows_valid = true;
     }

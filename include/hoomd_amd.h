@@ -871,7 +871,9 @@ int hmd_tile_slots(const hmd_tile_geom_t* geom, unsigned int* d_slot_of, void* s
 int hmd_tile_refresh(const hmd_scalar4* d_pos, const unsigned int* d_slot_of, hmd_scalar4* d_cpos, unsigned int n, void* stream);
 
 /* Returns HMD_OK and the LDS capacity to use when the tile path can serve this cell grid, else
-   HMD_ERR_UNSUPPORTED (use the row-based entry points).  cell_Nmax: slots per cell (cli.w). */
+   HMD_ERR_UNSUPPORTED (use the row-based entry points).  cell_Nmax: slots per cell (cli.w).  With more than one
+   particle type the rows carry the candidate's type beside its slot: at most 8 types, and the capacity is capped at
+   2751 candidates per 64-cell region (a build that meets a fuller region raises the overflow word). */
 int hmd_nlist_tiles_supported(const hmd_index3d_t* ci, const hmd_box_t* box, unsigned int cell_Nmax, unsigned int ntypes,
                               unsigned int* capacity_out);
 
@@ -922,6 +924,8 @@ typedef struct
     unsigned int* d_nlist;
     unsigned int N;
     hmd_box_t box;
+    unsigned int ntypes;             /* as given to hmd_compute_nlist_tiles: rows built for more than one type carry the
+                                        candidate's type in the top three bits of an entry, the slot in the low 13 */
     } hmd_tiles_to_rows_args_t;
 int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, void* stream);
 

@@ -26,13 +26,13 @@ def expanded_sets(K, tl, N, gbox):
                              tl["head"].cpu().numpy().view(np.uint64)[:N])
 
 
-@pytest.mark.parametrize("n,ntypes", [(9, 1), (12, 1), (13, 2), (16, 2), (40, 1)])
+@pytest.mark.parametrize("n,ntypes", [(9, 1), (12, 1), (13, 2), (16, 2), (40, 1), (12, 3)])
 def test_tile_neighbor_sets_match_oracle(K, A, n, ntypes):
     # 9 -> 3 cells per side (every region wraps onto the whole box), 13 -> odd grid (4 cells, last block half empty)
     xyz, typ, L = liquid(n, ntypes=ntypes)
     N = len(xyz)
     gbox, obox = boxes(A, L)
-    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, -1.0]]
+    r_cut = [[2.5]] if ntypes == 1 else [[2.5, 2.0], [2.0, -1.0]] if ntypes == 2 else [[2.5, 2.0, 2.3], [2.0, -1.0, 1.8], [2.3, 1.8, 2.4]]
     pos = orc.pack_pos(xyz, typ)
     ref = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=True)
     tl, _, dim = tile_nlist(K, A, torch.from_numpy(pos).cuda(), N, gbox, obox, r_cut, 0.4)
@@ -144,14 +144,22 @@ def test_tile_ghost_layer_non_periodic_box(K, A):
 
 
 @pytest.mark.parametrize("shift_mode", [0, 1, 2])
-@pytest.mark.parametrize("ntypes", [1, 2])
+@pytest.mark.parametrize("ntypes", [1, 2, 3])
 def test_tile_lj_forces_match_oracle(K, A, shift_mode, ntypes):
+    # (rows for two and three types carry the neighbors' types in their entries; two types take the kernels that keep both
+    # parameter sets in registers, three the ones with tables in LDS)
     xyz, typ, L = liquid(14, ntypes=ntypes, seed=3 + ntypes)
     N = len(xyz)
     gbox, obox = boxes(A, L)
     pos = orc.pack_pos(xyz, typ)
     if ntypes == 1:
         r_cut, params, ron = [[2.5]], [orc.lj_params(1.0, 1.0)], [[2.0]]
+    elif ntypes == 3:
+        r_cut = [[2.5, 2.0, 2.3], [2.0, 2.2, 1.8], [2.3, 1.8, 2.4]]
+        eps = [[1.0, 0.8, 1.2], [0.8, 0.88, 0.6], [1.2, 0.6, 0.9]]
+        sig = [[1.0, 1.5, 0.9], [1.5, 0.5, 1.1], [0.9, 1.1, 0.95]]
+        params = [orc.lj_params(eps[i][j], sig[i][j]) for i in range(3) for j in range(3)]
+        ron = [[2.0, 1.5, 2.0], [1.5, 2.4, 1.2], [2.0, 1.2, 2.0]]
     else:
         r_cut = [[2.5, 2.0], [2.0, 2.2]]
         params = [orc.lj_params(1.0, 1.0), orc.lj_params(0.8, 1.5), orc.lj_params(0.8, 1.5), orc.lj_params(0.88, 0.5)]
