@@ -68,7 +68,15 @@ __global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
         return;
     const unsigned int idx = a.d_group_members ? a.d_group_members[g] : g;
 
-    const double4 f = hmd_ld4(a.d_net_force + idx);
+    double4 f = hmd_ld4(a.d_net_force + idx);
+    if (a.d_net_force2)
+        {
+        // the sum of two forces, as the net-force pass computes it (0 + f1 is f1)
+        const double4 f2 = hmd_ld4(a.d_net_force2 + idx);
+        f.x = HMD_ADD(f.x, f2.x);
+        f.y = HMD_ADD(f.y, f2.y);
+        f.z = HMD_ADD(f.z, f2.z);
+        }
     const double4 v = hmd_ld4(a.d_vel + idx);
     const double minv = 1.0 / v.w;
     hmd_scalar3 acc;
@@ -103,7 +111,16 @@ template<bool CHECK, bool ORTHO, bool STEP_TWO = true> __global__ void __launch_
         const unsigned int idx = a.one.d_group_members ? a.one.d_group_members[g] : g;
         double4 f = make_double4(0, 0, 0, 0);
         if (STEP_TWO)
+            {
             f = hmd_ld4(a.two.d_net_force + idx);
+            if (a.two.d_net_force2)
+                {
+                const double4 f2 = hmd_ld4(a.two.d_net_force2 + idx);
+                f.x = HMD_ADD(f.x, f2.x);
+                f.y = HMD_ADD(f.y, f2.y);
+                f.z = HMD_ADD(f.z, f2.z);
+                }
+            }
         moved = hmd_fused_step_particle<ORTHO, STEP_TWO>(a, idx, f, CHECK);
         }
     if (CHECK)

@@ -142,7 +142,7 @@ class StepOneArgs(C.Structure):
 
 class StepTwoArgs(C.Structure):
     _fields_ = [("d_vel", vp), ("d_accel", vp), ("d_group_members", vp), ("group_size", u32), ("d_net_force", vp),
-                ("block_size", u32), ("deltaT", f64), ("rescale_factor", f64)]
+                ("block_size", u32), ("deltaT", f64), ("rescale_factor", f64), ("d_net_force2", vp)]
 
 
 class ThermoArgs(C.Structure):

@@ -404,16 +404,17 @@ def step_one(pos, vel, accel, image, box, dt, rescale=1.0, group=None, limit=Non
     check(_abi.lib.hmd_nvt_rescale_step_one(C.byref(a), _stream(pos)), "hmd_nvt_rescale_step_one")
 
 
-def step_two(vel, accel, net_force, dt, rescale=1.0, group=None):
+def step_two(vel, accel, net_force, dt, rescale=1.0, group=None, net_force2=None):
     a = _abi.StepTwoArgs()
     a.d_vel, a.d_accel, a.d_group_members, a.d_net_force = ptr(vel), ptr(accel), ptr(group), ptr(net_force)
+    a.d_net_force2 = ptr(net_force2)
     a.group_size = vel.shape[0] if group is None else group.numel()
     a.deltaT, a.rescale_factor = float(dt), float(rescale)
     check(_abi.lib.hmd_nvt_rescale_step_two(C.byref(a), _stream(vel)), "hmd_nvt_rescale_step_two")
 
 
 def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, rescale_one=1.0, group=None, last_pos=None, rcut_max=None,
-               r_buff=0.0, checkn=1, publish=False, step_two=True, slot_of=None, cpos=None):
+               r_buff=0.0, checkn=1, publish=False, step_two=True, slot_of=None, cpos=None, net_force2=None):
     """hmd_nve_step_two_one_check (step_two=False: hmd_nvt_rescale_step_one_check, the first half step alone); returns
     (flag word, published 64-bit word) when the check is requested."""
     dev = pos.device
@@ -421,6 +422,7 @@ def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, resc
     n = pos.shape[0] if group is None else group.numel()
     a.two.d_vel, a.two.d_accel, a.two.d_group_members, a.two.d_net_force = ptr(vel), ptr(accel), ptr(group), ptr(net_force)
     a.two.group_size, a.two.deltaT, a.two.rescale_factor = n, float(dt), float(rescale_two)
+    a.two.d_net_force2 = ptr(net_force2)
     a.one.d_pos, a.one.d_vel, a.one.d_accel, a.one.d_image, a.one.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
     a.one.group_size, a.one.box, a.one.rescale_factor, a.one.deltaT = n, box, float(rescale_one), float(dt)
     res = pub = None

@@ -345,6 +345,12 @@ class ParticleData
         }
     Scalar4* netForce() const
         {
+        materializeNetForce();
+        return m_net_force.get();
+        }
+    //! the storage itself, for the pass that fills it
+    Scalar4* netForceStorage() const
+        {
         return m_net_force.get();
         }
     Scalar* netVirial() const
@@ -397,7 +403,34 @@ class ParticleData
         }
     Scalar4* netForceForIntegration() const
         {
+        materializeNetForce();
         return m_net_force_alias ? m_net_force_alias : m_net_force.get();
+        }
+    //! Two forces and no virial request: the integrator's kernels add the two arrays where they read them, and the net
+    //! force array is only filled (by `sum`, the net-force pass) when somebody asks for it.
+    void setNetForcePair(const Scalar4* f1, const Scalar4* f2, std::function<void()> sum)
+        {
+        m_pair_f1 = f1;
+        m_pair_f2 = f2;
+        m_pair_sum = sum;
+        }
+    //! the two arrays whose sum is the net force, while that sum has not been stored
+    bool getNetForcePair(const Scalar4*& f1, const Scalar4*& f2) const
+        {
+        if (!m_pair_sum)
+            return false;
+        f1 = m_pair_f1;
+        f2 = m_pair_f2;
+        return true;
+        }
+    void materializeNetForce() const
+        {
+        if (m_pair_sum)
+            {
+            auto sum = std::move(m_pair_sum);
+            m_pair_sum = nullptr;
+            sum();
+            }
         }
 
     bool isAccelSet() const
@@ -484,6 +517,9 @@ class ParticleData
     Scalar4* m_net_force_alias = nullptr;
     DisplacementCheckHook m_check_hook;
     StepRiderSource m_rider_source;
+    const Scalar4* m_pair_f1 = nullptr;
+    const Scalar4* m_pair_f2 = nullptr;
+    mutable std::function<void()> m_pair_sum;
     uint64_t m_rider_done_tstep = ~0ull;
     bool m_accel_set = false;
     unsigned int m_flags = 0;
@@ -1508,6 +1544,7 @@ class IntegratorTwoStep
     private:
     void computeAccelerations(uint64_t timestep);
     bool fillStepRider(hmd_fused_step_args_t& a, uint64_t timestep);
+    void sumNetForce(bool virial);
     std::shared_ptr<SystemDefinition> m_sysdef;
     std::shared_ptr<ParticleData> m_pdata;
     Scalar m_deltaT;

@@ -79,7 +79,14 @@ void TwoStepConstantVolumeGPU::integrateStepTwo(uint64_t timestep)
     a.d_accel = m_pdata->accel();
     a.d_group_members = m_group->getIndexArray();
     a.group_size = m_group->getNumMembers();
-    a.d_net_force = m_pdata->netForceForIntegration();
+    const Scalar4 *f1 = nullptr, *f2 = nullptr;
+    if (m_pdata->getNetForcePair(f1, f2))
+        {
+        a.d_net_force = f1;
+        a.d_net_force2 = f2;
+        }
+    else
+        a.d_net_force = m_pdata->netForceForIntegration();
     a.deltaT = m_deltaT;
     a.rescale_factor = rescale[0];
     ScopedKernelTimer t("step_two");
@@ -101,7 +108,14 @@ void TwoStepConstantVolumeGPU::integrateStepTwoOne(uint64_t timestep)
     a.two.d_accel = nullptr;
     a.two.d_group_members = m_group->getIndexArray();
     a.two.group_size = m_group->getNumMembers();
-    a.two.d_net_force = m_pdata->netForceForIntegration();
+    const Scalar4 *f1 = nullptr, *f2 = nullptr;
+    if (m_pdata->getNetForcePair(f1, f2))
+        {
+        a.two.d_net_force = f1;
+        a.two.d_net_force2 = f2;
+        }
+    else
+        a.two.d_net_force = m_pdata->netForceForIntegration();
     a.two.deltaT = m_deltaT;
     a.two.rescale_factor = 1.0;
     a.one.d_pos = m_pdata->pos();
@@ -131,6 +145,7 @@ IntegratorTwoStep::IntegratorTwoStep(std::shared_ptr<SystemDefinition> sysdef, S
 
 IntegratorTwoStep::~IntegratorTwoStep()
     {
+    m_pdata->setNetForcePair(nullptr, nullptr, nullptr);
     m_pdata->aliasNetForce(nullptr);
     m_pdata->setStepRiderSource(nullptr);
     }
@@ -203,6 +218,7 @@ std::array<double, 3> IntegratorTwoStep::computeLinearMomentum()
 // identity: the integrator then reads that force array directly instead of copying it.
 void IntegratorTwoStep::computeNetForceGPU(uint64_t timestep)
     {
+    m_pdata->setNetForcePair(nullptr, nullptr, nullptr); // (a sum of the previous step's forces nobody asked for)
     for (auto& f : m_forces)
         f->compute(timestep);
 
@@ -228,15 +244,29 @@ void IntegratorTwoStep::computeNetForceGPU(uint64_t timestep)
     const unsigned int nparticles = m_pdata->getN() + m_pdata->getNGhosts();
     if (m_forces.empty())
         {
-        hipCheck(hipMemsetAsync(m_pdata->netForce(), 0, sizeof(Scalar4) * nparticles, 0), "zero net force");
+        hipCheck(hipMemsetAsync(m_pdata->netForceStorage(), 0, sizeof(Scalar4) * nparticles, 0), "zero net force");
         return;
         }
+    if (m_forces.size() == 2 && !virial)
+        {
+        // Two forces, no virial: the half steps add the two arrays where they read them (hmd_step_two_args_t::
+        // d_net_force2), and the net-force array is filled only when somebody asks for it (thermo, accelerations).
+        m_pdata->setNetForcePair(m_forces[0]->getForceArray(), m_forces[1]->getForceArray(), [this]() { sumNetForce(false); });
+        return;
+        }
+    sumNetForce(virial);
+    }
+
+// hoomd/Integrator.cc:344-560: the net-force pass
+void IntegratorTwoStep::sumNetForce(bool virial)
+    {
+    const unsigned int nparticles = m_pdata->getN() + m_pdata->getNGhosts();
     ScopedKernelTimer t("sum_net_force");
     for (size_t base = 0; base < m_forces.size(); base += 6)
         {
         hmd_sum_net_force_args_t a;
         std::memset(&a, 0, sizeof(a));
-        a.d_net_force = m_pdata->netForce();
+        a.d_net_force = m_pdata->netForceStorage();
         a.d_net_virial = m_pdata->netVirial();
         a.net_virial_pitch = m_pdata->netVirialPitch();
         for (size_t k = 0; k < 6 && base + k < m_forces.size(); k++)

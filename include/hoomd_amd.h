@@ -474,6 +474,11 @@ typedef struct
     unsigned int block_size;
     double deltaT;
     double rescale_factor;
+    /* Optional: a second force array.  The net force is then d_net_force + d_net_force2, as
+       hmd_integrator_sum_net_force would have left it for two forces (hoomd/Integrator.cu:67-166), added where it is
+       read: a run with two forces and no virial request needs no pass of its own for the sum.  Also honoured by
+       hmd_nve_step_two_one_check (two.d_net_force2). */
+    const hmd_scalar4* d_net_force2;
     } hmd_step_two_args_t;
 int hmd_nvt_rescale_step_two(const hmd_step_two_args_t* args, void* stream);
 

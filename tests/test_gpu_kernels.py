@@ -519,6 +519,37 @@ def test_fused_half_steps_and_check_match_the_separate_drivers(K, A):
     assert np.array_equal(tp.cpu().numpy(), p) and np.array_equal(tv.cpu().numpy(), v) and np.array_equal(ta.cpu().numpy(), a_)
 
 
+def test_half_steps_add_two_force_arrays_like_the_net_force_pass(K, A):
+    """d_net_force2: the second half step, alone and joined with the next first half step, adds two force arrays where it
+    reads them; bit-identical to hmd_integrator_sum_net_force followed by the same pass on the sum."""
+    xyz, typ, L = liquid(10, seed=31)
+    N = len(xyz)
+    rng = np.random.default_rng(8)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    image = np.zeros((N, 3), dtype=np.int32)
+    f1 = np.concatenate([rng.normal(0, 7.0, (N, 3)), rng.normal(-3, 1, (N, 1))], 1)
+    f2 = np.concatenate([rng.normal(0, 30.0, (N, 3)), rng.normal(5, 1, (N, 1))], 1)
+    f2[:5, :3] = -f1[:5, :3]  # sums that cancel
+    tf1, tf2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    nf, _ = K.sum_net_force([tf1, tf2])
+    # the second half step alone
+    va, vb = torch.from_numpy(vel.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+    aa, ab = torch.zeros((N, 3), dtype=torch.float64, device="cuda"), torch.zeros((N, 3), dtype=torch.float64, device="cuda")
+    K.step_two(va, aa, nf, 0.005)
+    K.step_two(vb, ab, tf1, 0.005, net_force2=tf2)
+    assert np.array_equal(va.cpu().numpy(), vb.cpu().numpy()) and np.array_equal(aa.cpu().numpy(), ab.cpu().numpy())
+    # joined with the next first half step
+    out = []
+    for kw in (dict(net_force=nf), dict(net_force=tf1, net_force2=tf2)):
+        tp, tv, ta, ti = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, np.zeros((N, 3)), image))
+        K.fused_step(tp, tv, ta, ti, kw["net_force"], gbox, 0.005, net_force2=kw.get("net_force2"))
+        out.append((tp.cpu().numpy(), tv.cpu().numpy(), ta.cpu().numpy(), ti.cpu().numpy()))
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_first_half_step_with_check_and_slot_copy_matches_the_separate_drivers(K, A):
     """hmd_nvt_rescale_step_one_check: step one with a thermostat's rescaling factor + distance check + slot-ordered
     position copy in one kernel, bit-identical to the drivers run one after the other."""
