@@ -165,6 +165,32 @@ bool CellListGPU::checkConditions()
     {
     unsigned int h[3];
     m_readback.read(reinterpret_cast<const unsigned int*>(m_conditions.get()), 3, h, "cell list conditions");
+    return evaluateConditions(h);
+    }
+
+// The check that compute() left to the consumer (setDeferConditions): true when the list had overflowed.  It has then
+// been computed again, with the check, so what the consumer built from the truncated list must be built again.
+bool CellListGPU::finishConditions()
+    {
+    if (!m_conditions_pending)
+        return false;
+    m_conditions_pending = false;
+    unsigned int h[3];
+    m_readback.finish(h, "cell list conditions");
+    bool overflowed = evaluateConditions(h);
+    const bool any = overflowed;
+    while (overflowed)
+        {
+        initializeAll();
+        m_conditions.zero();
+        computeCellList();
+        overflowed = checkConditions();
+        }
+    return any;
+    }
+
+bool CellListGPU::evaluateConditions(const unsigned int (&h)[3])
+    {
     bool result = false;
     if (h[0] > m_Nmax)
         {
@@ -227,6 +253,15 @@ void CellListGPU::compute(uint64_t timestep)
         }
     if (shouldCompute(timestep) || force)
         {
+        if (m_defer_conditions)
+            {
+            if (m_conditions_pending) // (nobody asked about the previous computation)
+                finishConditions();
+            computeCellList();
+            m_readback.begin(reinterpret_cast<const unsigned int*>(m_conditions.get()), 3);
+            m_conditions_pending = true;
+            return;
+            }
         bool overflowed = false;
         do
             {

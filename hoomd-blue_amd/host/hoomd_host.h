@@ -155,10 +155,14 @@ class WordReadback
     WordReadback() : m_pinned(128) { }
     //! blocks until the words have arrived; n <= 64
     void read(const unsigned int* d_words, unsigned int n, unsigned int* out, const char* what);
+    //! the same in two halves: begin() queues the publication behind the work that produces the words, finish() waits
+    //! for it -- in between the caller queues more work, so the device does not sit idle while the host looks
+    void begin(const unsigned int* d_words, unsigned int n);
+    void finish(unsigned int* out, const char* what);
 
     private:
     PinnedWords m_pinned; // 64 slots of 8 bytes
-    unsigned int m_stamp = 0;
+    unsigned int m_stamp = 0, m_n = 0;
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -801,6 +805,15 @@ class CellListGPU : public Compute
         m_sort = s;
         m_params_changed = true;
         }
+    //! A consumer that checks conditions of its own right after using the list (the neighbor-list build) can take the
+    //! cell list's overflow check along: compute() then queues the kernel and returns, and finishConditions() tells
+    //! later whether the list had overflowed -- in which case it has been computed again with more room and whatever
+    //! was built from it has to be built again.  Saves one wait of the host per rebuild.
+    void setDeferConditions(bool d)
+        {
+        m_defer_conditions = d;
+        }
+    bool finishConditions();
     void setMultiple(unsigned int m)
         {
         m_multiple = m ? m : 1;
@@ -860,6 +873,8 @@ class CellListGPU : public Compute
     void initializeCellAdj();
     void computeCellList();
     bool checkConditions();
+    bool evaluateConditions(const unsigned int (&h)[3]);
+    bool m_defer_conditions = false, m_conditions_pending = false;
 
     Scalar m_nominal_width = 0;
     unsigned int m_radius = 1, m_Nmax = 0, m_multiple = 1, m_n_adj = 0, m_nmax_headroom = 0;

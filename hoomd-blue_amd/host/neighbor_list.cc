@@ -38,6 +38,7 @@ NeighborListGPUBinned::NeighborListGPUBinned(std::shared_ptr<SystemDefinition> s
     m_cl->setComputeTypeBody(true);
     m_cl->setComputeIdx(true); // the tile kernels number candidates through the index array
     m_cl->setFlagIndex();
+    m_cl->setDeferConditions(true);
 
     m_pdata->setDisplacementCheckHook([this](hmd_fused_step_args_t& a, uint64_t timestep) { offerFusedPass(a, timestep); });
     m_sort_slot = m_pdata->getParticleSortSignal().connect([this]() { forceUpdate(); });
@@ -726,6 +727,10 @@ void NeighborListGPUBinned::compute(uint64_t timestep)
             {
             buildNlist(timestep);
             overflowed = checkConditions();
+            // the cell list's own overflow check rode along (one wait of the host instead of two): when it had
+            // overflowed it has been computed again by now, and the rows are built again from the complete list
+            if (m_cl->finishConditions())
+                overflowed = true;
             if (overflowed)
                 {
                 buildHeadList();

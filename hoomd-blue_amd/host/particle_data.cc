@@ -51,14 +51,25 @@ unsigned int* PinnedWords::deviceView()
 
 void WordReadback::read(const unsigned int* d_words, unsigned int n, unsigned int* out, const char* what)
     {
-    if (n == 0)
-        return;
+    begin(d_words, n);
+    finish(out, what);
+    }
+
+void WordReadback::begin(const unsigned int* d_words, unsigned int n)
+    {
     if (n > 64)
         throw std::runtime_error("WordReadback: more than 64 words");
+    m_n = n;
+    if (n == 0)
+        return;
     m_stamp++;
     abiCheck(hmd_publish_words(d_words, n, reinterpret_cast<unsigned long long*>(m_pinned.deviceView()), m_stamp, nullptr), "hmd_publish_words");
+    }
+
+void WordReadback::finish(unsigned int* out, const char* what)
+    {
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_pinned.get());
-    for (unsigned int k = 0; k < n; k++)
+    for (unsigned int k = 0; k < m_n; k++)
         out[k] = (unsigned int)pollStampedWord(h + k, m_stamp, what);
     }
 
