@@ -481,6 +481,12 @@ __device__ __forceinline__ nl_pref_t nl_pref_thresholds(double rl, double rl2, d
     return t;
     }
 
+// bytes of the cell-start flags of one wave: one per candidate of 27 full cells, rounded up to whole slabs
+__host__ __device__ constexpr unsigned int nl_pref_flag_bytes(unsigned int cell_Nmax)
+    {
+    return (27u * cell_Nmax + 63u) / 64u * 64u + 64u;
+    }
+
 template<bool TILE, bool EXCL, bool TWO, int MAXK>
 __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
                                                               unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
@@ -493,9 +499,16 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
     double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
     unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * NL_WAVES);
     unsigned int* s_rowbuf = s_tileoff_all + 64 * NL_WAVES;
+    // which adjacent cell a candidate belongs to, without a search: a byte per candidate number that is set where a
+    // (non-empty) cell starts, and the non-empty cells in order
+    unsigned int* s_map_all = s_rowbuf + NL_ROWBUF * NL_WAVES;
+    const unsigned int flag_bytes = nl_pref_flag_bytes(a.cli.w);
+    unsigned char* s_flag_all = reinterpret_cast<unsigned char*>(s_map_all + 32 * NL_WAVES);
 
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int* s_map = s_map_all + 32 * wave;
+    unsigned char* s_flag = s_flag_all + flag_bytes * wave;
     unsigned int* s_excl = s_excl_all + 64 * wave;
     unsigned int* s_cell = s_cell_all + 64 * wave;
     double* s_shift = s_shift_all + 3 * 64 * wave;
@@ -581,6 +594,17 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
     s_cell[lane] = adj_cell;
     // where the home cell's own members start in the candidate list (for the self exclusion): offset (0, 0, 0) is lane 13
     const unsigned int self_first = rl_u(incl - adj_size, 13u);
+        {
+        for (unsigned int i = 4u * lane; i < flag_bytes; i += 256u)
+            *reinterpret_cast<unsigned int*>(s_flag + i) = 0u;
+        const bool nonempty = adj_size != 0u; // (lanes 27 and up have no cell: size 0)
+        const unsigned long long ne = __ballot(nonempty);
+        if (nonempty)
+            {
+            s_map[hmd_rank_in_mask(ne)] = lane;
+            s_flag[incl - adj_size] = 1;
+            }
+        }
 
     unsigned int tile_pad = 0, tile_hoff = 0, tile_grp0 = 0;
     const unsigned int tile_row_cap = row_pieces * hmd::TL_PIECE;
@@ -658,6 +682,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         const double Ox = rl_d(hx, 0), Oy = rl_d(hy, 0), Oz = rl_d(hz, 0);
         const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
 
+        unsigned int cells_before = 0; // non-empty cells that start before the slab being looked up (slabs are taken in order)
         for (unsigned int pbase = 0; pbase < T; pbase += MAXK * 64)
             {
             const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(MAXK * 64)));
@@ -693,8 +718,18 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     const unsigned int k = pbase + (b0 + q) * 64 + lane;
                     lo_[q] = 0;
                     w_[q] = 0xffffffffu;
-                    if ((unsigned int)((b0 + q) * 64) < Tp && k < T)
-                        w_[q] = cand_lookup(k, lo_[q]);
+                    if ((unsigned int)((b0 + q) * 64) < Tp)
+                        {
+                        // the cell of candidate k: as many non-empty cells start at or before k as flags are set up to k
+                        const unsigned long long starts = __ballot(s_flag[k] != 0);
+                        const unsigned int below = hmd_rank_in_mask(starts) + (unsigned int)((starts >> lane) & 1ull);
+                        if (k < T)
+                            {
+                            lo_[q] = s_map[cells_before + below - 1u];
+                            w_[q] = hmd_idx2(a.cli, k - s_excl[lo_[q]], s_cell[lo_[q]]);
+                            }
+                        cells_before += (unsigned int)__popcll(starts);
+                        }
                     }
                 double2 vxy[NL_BATCH], vzw[NL_BATCH];
                 unsigned int vty[TWO ? NL_BATCH : 1];
@@ -1673,7 +1708,7 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
         const double gw[3] = {a.ghost_width.x, a.ghost_width.y, a.ghost_width.z};
         for (int d = 0; d < 3; d++)
             wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
-        const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF) + sizeof(double) * 3 * 64) * NL_WAVES;
+        const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF + 32) + sizeof(double) * 3 * 64 + nl_pref_flag_bytes(a.cli.w)) * NL_WAVES;
 // candidates in registers: 12 slabs of 64 cover the 27 cells of liquids up to 28 particles per cell in one pass (the
 // LJ liquid has 21.5); denser systems (the binary mixture at density 1.2: 29) get 14 slabs, at three waves per SIMD
 // instead of four, rather than a second pass over a handful of candidates.  Decided by the mean occupancy.
