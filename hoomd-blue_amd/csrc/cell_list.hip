@@ -66,8 +66,11 @@ __global__ void __launch_bounds__(256) cell_list_kernel(hmd_cell_list_args_t a)
             }
         }
 
-    // wave-aggregated slot reservation
-    unsigned int slot = 0;
+    // wave-aggregated slot reservation: the lanes are grouped by cell first (no memory access), then the leaders of
+    // all groups reserve their slots with one atomic instruction, so a wave waits for one round trip to the counters
+    // and not for one per distinct cell
+    unsigned int slot = 0, group_size = 0;
+    int my_leader = 0;
     unsigned long long todo = __ballot(active);
     while (todo)
         {
@@ -75,14 +78,18 @@ __global__ void __launch_bounds__(256) cell_list_kernel(hmd_cell_list_args_t a)
         const unsigned int lbin = __shfl(bin, leader);
         const bool mine = active && (bin == lbin);
         const unsigned long long peers = __ballot(mine);
-        unsigned int base = 0;
-        if ((int)(threadIdx.x & 63) == leader)
-            base = atomicAdd(&a.d_cell_size[lbin], (unsigned int)__popcll(peers));
-        base = __shfl(base, leader);
         if (mine)
-            slot = base + hmd_rank_in_mask(peers);
+            {
+            slot = hmd_rank_in_mask(peers);
+            group_size = (unsigned int)__popcll(peers);
+            my_leader = leader;
+            }
         todo &= ~peers;
         }
+    unsigned int base = 0;
+    if (active && (int)(threadIdx.x & 63) == my_leader)
+        base = atomicAdd(&a.d_cell_size[bin], group_size);
+    slot += __shfl(base, my_leader);
 
     if (!active)
         return;

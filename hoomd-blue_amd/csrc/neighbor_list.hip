@@ -1608,26 +1608,65 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
     const unsigned int nb = nbx * nby * nbz;
     const unsigned int per = (nb + BG_THREADS - 1) / BG_THREADS;
     const unsigned int first = min(threadIdx.x * per, nb), last = min(first + per, nb);
-    auto groups_of = [&](unsigned int b) -> unsigned int
+    // Cells past the edge of the grid: the load goes to a cell at the edge instead, without a branch, and the values pass
+    // through an empty asm statement before they are used -- otherwise the compiler moves every load behind the test of
+    // its cell and waits for each in turn (eight round trips to memory per block).
+    static_assert(hmd::TL_NH == 8, "eight home cells per block");
+    auto load_sizes = [&](unsigned int b, unsigned int (&v)[8])
+    {
+        const unsigned int cx0 = hmd::TB_X * (b % nbx), cy0 = hmd::TB_Y * ((b / nbx) % nby), cz0 = hmd::TB_Z * (b / (nbx * nby));
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            {
+            const unsigned int x = cx0 + q % hmd::TB_X, y = cy0 + (q / hmd::TB_X) % hmd::TB_Y, z = cz0 + q / (hmd::TB_X * hmd::TB_Y);
+            v[q] = d_cell_size[(min(z, ci.d - 1u) * ci.h + min(y, ci.h - 1u)) * ci.w + min(x, ci.w - 1u)];
+            }
+    };
+    auto arrived = [](unsigned int (&v)[8], unsigned int (&w)[8])
+    { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])); };
+    auto count_groups = [&](unsigned int b, const unsigned int (&v)[8]) -> unsigned int
     {
         const unsigned int cx0 = hmd::TB_X * (b % nbx), cy0 = hmd::TB_Y * ((b / nbx) % nby), cz0 = hmd::TB_Z * (b / (nbx * nby));
         unsigned int members = 0;
 #pragma unroll
-        for (int q = 0; q < hmd::TL_NH; q++)
+        for (int q = 0; q < 8; q++)
             {
             const unsigned int x = cx0 + q % hmd::TB_X, y = cy0 + (q / hmd::TB_X) % hmd::TB_Y, z = cz0 + q / (hmd::TB_X * hmd::TB_Y);
-            if (x < ci.w && y < ci.h && z < ci.d)
-                members += min(d_cell_size[(z * ci.h + y) * ci.w + x], cell_Nmax);
+            members += (x < ci.w && y < ci.h && z < ci.d) ? min(v[q], cell_Nmax) : 0u;
             }
         return (members + hmd::TL_GROUP - 1) / hmd::TL_GROUP;
+    };
+    auto groups_of = [&](unsigned int b) -> unsigned int
+    {
+        unsigned int v[8], w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        load_sizes(b, v);
+        arrived(v, w);
+        return count_groups(b, v);
     };
     // counts first, with neighboring threads on neighboring blocks (when they fit the LDS the launcher provided):
     // every thread then sums and later numbers its run of consecutive blocks from LDS
     extern __shared__ unsigned int s_groups[];
     if (cached)
         {
-        for (unsigned int b = threadIdx.x; b < nb; b += BG_THREADS)
-            s_groups[b] = groups_of(b);
+        // four blocks per trip: 32 loads in flight per thread
+        for (unsigned int b = threadIdx.x; b < nb; b += 4u * BG_THREADS)
+            {
+            const unsigned int b1 = min(b + BG_THREADS, nb - 1u), b2 = min(b + 2u * BG_THREADS, nb - 1u), b3 = min(b + 3u * BG_THREADS, nb - 1u);
+            unsigned int v0[8], v1[8], v2[8], v3[8];
+            load_sizes(b, v0);
+            load_sizes(b1, v1);
+            load_sizes(b2, v2);
+            load_sizes(b3, v3);
+            arrived(v0, v1);
+            arrived(v2, v3);
+            s_groups[b] = count_groups(b, v0);
+            if (b + BG_THREADS < nb)
+                s_groups[b1] = count_groups(b1, v1);
+            if (b + 2u * BG_THREADS < nb)
+                s_groups[b2] = count_groups(b2, v2);
+            if (b + 3u * BG_THREADS < nb)
+                s_groups[b3] = count_groups(b3, v3);
+            }
         __syncthreads();
         }
     unsigned int mine = 0;
