@@ -184,6 +184,13 @@ static inline bool hmd_box_is_ortho(const hmd_box_t& b)
     return b.xy == 0.0 && b.xz == 0.0 && b.yz == 0.0;
     }
 
+// the factor of the first half step: the one the host passed, or sqrt(target energy / kinetic energy) with the kinetic
+// energy read where the thermo sums left it (every lane reads the same word)
+__device__ __forceinline__ double hmd_rescale_factor(const hmd_step_one_args_t& a)
+    {
+    return a.d_rescale_ke ? sqrt(a.rescale_gamma / *a.d_rescale_ke) : a.rescale_factor;
+    }
+
 // number of lanes below this one in a 64-bit ballot mask
 __device__ __forceinline__ unsigned int hmd_rank_in_mask(unsigned long long mask)
     {

@@ -25,9 +25,10 @@ __global__ void __launch_bounds__(256) step_one_kernel(hmd_step_one_args_t a)
     const hmd_scalar3 acc = a.d_accel[idx];
 
     // v = v + (1/2 a) dt ; v *= rescale
-    double vx = HMD_MUL(HMD_ADD(v.x, HMD_MUL(HMD_MUL(0.5, acc.x), a.deltaT)), a.rescale_factor);
-    double vy = HMD_MUL(HMD_ADD(v.y, HMD_MUL(HMD_MUL(0.5, acc.y), a.deltaT)), a.rescale_factor);
-    double vz = HMD_MUL(HMD_ADD(v.z, HMD_MUL(HMD_MUL(0.5, acc.z), a.deltaT)), a.rescale_factor);
+    const double rs = hmd_rescale_factor(a);
+    double vx = HMD_MUL(HMD_ADD(v.x, HMD_MUL(HMD_MUL(0.5, acc.x), a.deltaT)), rs);
+    double vy = HMD_MUL(HMD_ADD(v.y, HMD_MUL(HMD_MUL(0.5, acc.y), a.deltaT)), rs);
+    double vz = HMD_MUL(HMD_ADD(v.z, HMD_MUL(HMD_MUL(0.5, acc.z), a.deltaT)), rs);
 
     if (a.use_limit)
         {
@@ -61,13 +62,9 @@ __global__ void __launch_bounds__(256) step_one_kernel(hmd_step_one_args_t a)
         }
     }
 
-__global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
+// the second half step of one particle; returns the new velocity (w = mass) and the particle's potential energy
+__device__ __forceinline__ double4 step_two_particle(const hmd_step_two_args_t& a, unsigned int idx, double& pe)
     {
-    const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.group_size)
-        return;
-    const unsigned int idx = a.d_group_members ? a.d_group_members[g] : g;
-
     double4 f = hmd_ld4(a.d_net_force + idx);
     if (a.d_net_force2)
         {
@@ -89,6 +86,17 @@ __global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
     const double vz = HMD_ADD(HMD_MUL(v.z, a.rescale_factor), HMD_MUL(hdt, acc.z));
     hmd_st4(a.d_vel + idx, vx, vy, vz, v.w);
     a.d_accel[idx] = acc;
+    pe = f.w;
+    return make_double4(vx, vy, vz, v.w);
+    }
+
+__global__ void __launch_bounds__(256) step_two_kernel(hmd_step_two_args_t a)
+    {
+    const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.group_size)
+        return;
+    double pe;
+    step_two_particle(a, a.d_group_members ? a.d_group_members[g] : g, pe);
     }
 
 // step two of t, step one of t+1 and the distance check in one pass (same arithmetic, same order, as the
@@ -245,6 +253,31 @@ __global__ void __launch_bounds__(TH_BLOCK) thermo_partial_kernel(hmd_thermo_arg
         }
     }
 
+// the second half step and the partial sums of thermo_partial_kernel (same particles per thread, same order) in one pass
+__global__ void __launch_bounds__(TH_BLOCK) step_two_thermo_kernel(hmd_step_two_args_t s, hmd_thermo_args_t a)
+    {
+    __shared__ double s_part[(TH_BLOCK / 64) * TH_VALS];
+    double v[TH_VALS] = {0, 0, 0, 0, 0, 0};
+    for (unsigned int g = blockIdx.x * TH_BLOCK + threadIdx.x; g < a.group_size; g += TH_BLOCKS * TH_BLOCK)
+        {
+        const unsigned int idx = a.d_group_members ? a.d_group_members[g] : g;
+        double pe;
+        const double4 vel = step_two_particle(s, idx, pe);
+        v[0] += 0.5 * vel.w * (vel.x * vel.x + vel.y * vel.y + vel.z * vel.z);
+        v[1] += pe;
+        v[3] += vel.w * vel.x;
+        v[4] += vel.w * vel.y;
+        v[5] += vel.w * vel.z;
+        }
+    block_reduce6(v, s_part);
+    if (threadIdx.x == 0)
+        {
+        double* out = reinterpret_cast<double*>(a.d_scratch) + blockIdx.x * TH_VALS;
+        for (unsigned int q = 0; q < TH_VALS; q++)
+            out[q] = v[q];
+        }
+    }
+
 __global__ void __launch_bounds__(TH_BLOCK) thermo_final_kernel(hmd_thermo_args_t a)
     {
     __shared__ double s_part[(TH_BLOCK / 64) * TH_VALS];
@@ -260,6 +293,9 @@ __global__ void __launch_bounds__(TH_BLOCK) thermo_final_kernel(hmd_thermo_args_
             a.d_out[q] = v[q];
         a.d_out[6] = 0.0;
         a.d_out[7] = 0.0;
+        if (a.d_out_host)
+            for (unsigned int q = 0; q < 8; q++)
+                __hip_atomic_store(a.d_out_host + q, q < TH_VALS ? v[q] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     } // namespace
@@ -396,5 +432,21 @@ extern "C" int hmd_compute_thermo(const hmd_thermo_args_t* args, void* stream)
                 "hmd_compute_thermo: out, scratch, vel and net_force are required");
     hipLaunchKernelGGL(thermo_partial_kernel, dim3(TH_BLOCKS), dim3(TH_BLOCK), 0, (hipStream_t)stream, *args);
     hipLaunchKernelGGL(thermo_final_kernel, dim3(1), dim3(TH_BLOCK), 0, (hipStream_t)stream, *args);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_nvt_rescale_step_two_thermo(const hmd_step_two_args_t* two, const hmd_thermo_args_t* thermo, void* stream)
+    {
+    HMD_REQUIRE(two && thermo, HMD_ERR_INVALID_ARGUMENT, "hmd_nvt_rescale_step_two_thermo: two or thermo is NULL");
+    HMD_REQUIRE(two->d_vel && two->d_accel && two->d_net_force, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_nvt_rescale_step_two_thermo: vel, accel and net_force are required");
+    HMD_REQUIRE(thermo->d_out && thermo->d_scratch, HMD_ERR_INVALID_ARGUMENT, "hmd_nvt_rescale_step_two_thermo: out and scratch are required");
+    HMD_REQUIRE(thermo->d_vel == two->d_vel && thermo->d_net_force == two->d_net_force && thermo->d_group_members == two->d_group_members
+                    && thermo->group_size == two->group_size,
+                HMD_ERR_UNSUPPORTED, "hmd_nvt_rescale_step_two_thermo: the sums must be over the group, velocities and net force of the half step");
+    HMD_REQUIRE(!thermo->d_net_virial && !two->d_net_force2, HMD_ERR_UNSUPPORTED,
+                "hmd_nvt_rescale_step_two_thermo: virial sums and a second force array need the separate drivers");
+    hipLaunchKernelGGL(step_two_thermo_kernel, dim3(TH_BLOCKS), dim3(TH_BLOCK), 0, (hipStream_t)stream, *two, *thermo);
+    hipLaunchKernelGGL(thermo_final_kernel, dim3(1), dim3(TH_BLOCK), 0, (hipStream_t)stream, *thermo);
     return hmd_launch_status();
     }

@@ -120,7 +120,7 @@ static inline bool pft_step_supported(const hmd_pair_args_t& a, const hmd_fused_
         w = "the group must be every particle, without a displacement limit";
     else if (t.two.d_accel)
         w = "the accelerations are not stored (two.d_accel must be null)";
-    else if (t.one.rescale_factor != 1.0 || t.two.rescale_factor != 1.0 || t.one.deltaT != t.two.deltaT)
+    else if (t.one.rescale_factor != 1.0 || t.one.d_rescale_ke || t.two.rescale_factor != 1.0 || t.one.deltaT != t.two.deltaT)
         w = "no velocity rescaling, one time step length";
     else if (!hmd_box_is_ortho(t.one.box) || !(t.one.box.periodic[0] && t.one.box.periodic[1] && t.one.box.periodic[2]))
         w = "the box must be orthorhombic and periodic in all directions";

@@ -36,9 +36,10 @@ __device__ __forceinline__ bool hmd_fused_step_particle(const hmd_fused_step_arg
     else
         acc = a.one.d_accel[idx];
     // ---- step one (t+1) ----
-    vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), a.one.rescale_factor);
-    vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), a.one.rescale_factor);
-    vz = HMD_MUL(HMD_ADD(vz, HMD_MUL(HMD_MUL(0.5, acc.z), a.one.deltaT)), a.one.rescale_factor);
+    const double rs = hmd_rescale_factor(a.one);
+    vx = HMD_MUL(HMD_ADD(vx, HMD_MUL(HMD_MUL(0.5, acc.x), a.one.deltaT)), rs);
+    vy = HMD_MUL(HMD_ADD(vy, HMD_MUL(HMD_MUL(0.5, acc.y), a.one.deltaT)), rs);
+    vz = HMD_MUL(HMD_ADD(vz, HMD_MUL(HMD_MUL(0.5, acc.z), a.one.deltaT)), rs);
     double x = HMD_ADD(p.x, HMD_MUL(a.one.deltaT, vx));
     double y = HMD_ADD(p.y, HMD_MUL(a.one.deltaT, vy));
     double z = HMD_ADD(p.z, HMD_MUL(a.one.deltaT, vz));

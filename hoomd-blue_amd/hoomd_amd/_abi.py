@@ -137,7 +137,7 @@ class SumNetForceArgs(C.Structure):
 class StepOneArgs(C.Structure):
     _fields_ = [("d_pos", vp), ("d_vel", vp), ("d_accel", vp), ("d_image", vp), ("d_group_members", vp),
                 ("group_size", u32), ("box", Box), ("block_size", u32), ("rescale_factor", f64), ("deltaT", f64),
-                ("use_limit", C.c_int), ("maximum_displacement", f64)]
+                ("use_limit", C.c_int), ("maximum_displacement", f64), ("d_rescale_ke", vp), ("rescale_gamma", f64)]
 
 
 class StepTwoArgs(C.Structure):
@@ -147,7 +147,7 @@ class StepTwoArgs(C.Structure):
 
 class ThermoArgs(C.Structure):
     _fields_ = [("d_out", vp), ("d_scratch", vp), ("d_vel", vp), ("d_net_force", vp), ("d_net_virial", vp),
-                ("net_virial_pitch", C.c_size_t), ("d_group_members", vp), ("group_size", u32)]
+                ("net_virial_pitch", C.c_size_t), ("d_group_members", vp), ("group_size", u32), ("d_out_host", vp)]
 
 
 class CellOrderArgs(C.Structure):
@@ -288,6 +288,7 @@ _SIGNATURES = {
     "hmd_compute_accelerations": (C.c_int, [vp, vp, vp, u32, vp]),
     "hmd_thermo_scratch_bytes": (C.c_size_t, []),
     "hmd_compute_thermo": (C.c_int, [C.POINTER(ThermoArgs), vp]),
+    "hmd_nvt_rescale_step_two_thermo": (C.c_int, [C.POINTER(StepTwoArgs), C.POINTER(ThermoArgs), vp]),
     "hmd_cell_order_workspace_bytes": (C.c_size_t, [u32]),
     "hmd_cell_order": (C.c_int, [C.POINTER(CellOrderArgs), vp]),
     "hmd_gather_rows": (C.c_int, [vp, vp, vp, u32, u32, vp]),

@@ -394,8 +394,10 @@ def sum_net_force(forces, virials=None, net_force=None, net_virial=None, clear=T
     return nf, nv
 
 
-def step_one(pos, vel, accel, image, box, dt, rescale=1.0, group=None, limit=None):
+def step_one(pos, vel, accel, image, box, dt, rescale=1.0, group=None, limit=None, rescale_ke=None, rescale_gamma=0.0):
+    """rescale_ke: a device tensor whose first double is the kinetic energy; the factor is then sqrt(rescale_gamma / ke)"""
     a = _abi.StepOneArgs()
+    a.d_rescale_ke, a.rescale_gamma = ptr(rescale_ke), float(rescale_gamma)
     a.d_pos, a.d_vel, a.d_accel, a.d_image, a.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
     a.group_size = pos.shape[0] if group is None else group.numel()
     a.box, a.rescale_factor, a.deltaT = box, float(rescale), float(dt)
@@ -414,7 +416,7 @@ def step_two(vel, accel, net_force, dt, rescale=1.0, group=None, net_force2=None
 
 
 def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, rescale_one=1.0, group=None, last_pos=None, rcut_max=None,
-               r_buff=0.0, checkn=1, publish=False, step_two=True, slot_of=None, cpos=None, net_force2=None):
+               r_buff=0.0, checkn=1, publish=False, step_two=True, slot_of=None, cpos=None, net_force2=None, rescale_ke=None, rescale_gamma=0.0):
     """hmd_nve_step_two_one_check (step_two=False: hmd_nvt_rescale_step_one_check, the first half step alone); returns
     (flag word, published 64-bit word) when the check is requested."""
     dev = pos.device
@@ -425,6 +427,7 @@ def fused_step(pos, vel, accel, image, net_force, box, dt, rescale_two=1.0, resc
     a.two.d_net_force2 = ptr(net_force2)
     a.one.d_pos, a.one.d_vel, a.one.d_accel, a.one.d_image, a.one.d_group_members = ptr(pos), ptr(vel), ptr(accel), ptr(image), ptr(group)
     a.one.group_size, a.one.box, a.one.rescale_factor, a.one.deltaT = n, box, float(rescale_one), float(dt)
+    a.one.d_rescale_ke, a.one.rescale_gamma = ptr(rescale_ke), float(rescale_gamma)
     res = pub = None
     if last_pos is not None:
         res = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -464,6 +467,24 @@ def thermo(vel, net_force, net_virial=None, group=None):
     a.group_size = vel.shape[0] if group is None else group.numel()
     check(_abi.lib.hmd_compute_thermo(C.byref(a), _stream(vel)), "hmd_compute_thermo")
     return out.cpu().numpy()
+
+
+def step_two_thermo(vel, accel, net_force, dt, rescale=1.0, group=None):
+    """hmd_nvt_rescale_step_two_thermo: the second half step and the thermo sums of the new velocities in one pass;
+    returns the eight sums as a device tensor."""
+    dev = vel.device
+    out = torch.zeros(8, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(_abi.lib.hmd_thermo_scratch_bytes(), dtype=torch.uint8, device=dev)
+    s = _abi.StepTwoArgs()
+    s.d_vel, s.d_accel, s.d_group_members, s.d_net_force = ptr(vel), ptr(accel), ptr(group), ptr(net_force)
+    s.group_size = vel.shape[0] if group is None else group.numel()
+    s.deltaT, s.rescale_factor = float(dt), float(rescale)
+    a = _abi.ThermoArgs()
+    a.d_out, a.d_scratch, a.d_vel, a.d_net_force = ptr(out), ptr(scratch), ptr(vel), ptr(net_force)
+    a.net_virial_pitch = vel.shape[0]
+    a.d_group_members, a.group_size = ptr(group), s.group_size
+    check(_abi.lib.hmd_nvt_rescale_step_two_thermo(C.byref(s), C.byref(a), _stream(vel)), "hmd_nvt_rescale_step_two_thermo")
+    return out
 
 
 def cell_order(cl, N):

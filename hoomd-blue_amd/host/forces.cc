@@ -89,15 +89,13 @@ Scalar ForceCompute::calcEnergySum()
 // ---------------------------------------------------------------------------------------------
 ComputeThermoGPU::ComputeThermoGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ParticleGroup> group) : Compute(sysdef), m_group(group)
     {
+    *reinterpret_cast<double*>(m_host_copy.get()) = 1.0;
     m_out.resize(8);
     m_scratch.resize(hmd_thermo_scratch_bytes());
     }
 
-void ComputeThermoGPU::compute(uint64_t timestep)
+void ComputeThermoGPU::fillArgs(hmd_thermo_args_t& a)
     {
-    if (!shouldCompute(timestep))
-        return;
-    hmd_thermo_args_t a;
     std::memset(&a, 0, sizeof(a));
     a.d_out = m_out.get();
     a.d_scratch = m_scratch.get();
@@ -107,15 +105,48 @@ void ComputeThermoGPU::compute(uint64_t timestep)
     a.net_virial_pitch = m_pdata->netVirialPitch();
     a.d_group_members = m_group->getIndexArray();
     a.group_size = m_group->getNumMembers();
-        {
-        ScopedKernelTimer t("thermo");
-        abiCheck(hmd_compute_thermo(&a, nullptr), "hmd_compute_thermo");
-        }
+    a.d_out_host = reinterpret_cast<double*>(m_host_copy.deviceView());
+    }
+
+void ComputeThermoGPU::launch()
+    {
+    hmd_thermo_args_t a;
+    fillArgs(a);
+    ScopedKernelTimer t("thermo");
+    abiCheck(hmd_compute_thermo(&a, nullptr), "hmd_compute_thermo");
+    m_host_stale = true;
+    }
+
+void ComputeThermoGPU::fetch()
+    {
     m_out.download(m_vals.data(), 8);
+    m_host_stale = false;
     m_vals[1] += m_pdata->getExternalEnergy();
     m_vals[2] += m_pdata->getExternalVirial(0) + m_pdata->getExternalVirial(3) + m_pdata->getExternalVirial(5);
     if (m_allreduce_sum)
         m_allreduce_sum(m_vals.data(), 6);
+    }
+
+void ComputeThermoGPU::compute(uint64_t timestep)
+    {
+    if (shouldCompute(timestep))
+        launch();
+    if (m_host_stale)
+        fetch();
+    }
+
+void ComputeThermoGPU::computeAsync(uint64_t timestep)
+    {
+    if (shouldCompute(timestep))
+        launch();
+    }
+
+void ComputeThermoGPU::adoptQueuedValues(uint64_t timestep)
+    {
+    m_first_compute = false;
+    m_force_compute = false;
+    m_last_computed = timestep;
+    m_host_stale = true;
     }
 
 // hoomd/md/ComputeThermo.h:190-215: P = (2 K_trans + W) / (D V)
@@ -144,10 +175,31 @@ std::array<Scalar, 2> BussiThermostat::getRescalingFactorsOne(uint64_t timestep,
     const Scalar ntdof = m_thermo->getTranslationalDOF();
     if (ntdof != 0 && m_thermo->getTranslationalKineticEnergy() == 0)
         throw std::runtime_error("Bussi thermostat requires non-zero initial temperatures");
+    return {std::sqrt(drawTargetEnergy(timestep) / m_thermo->getTranslationalKineticEnergy()), 1.0};
+    }
+
+// the kinetic energy the thermostat sets: gamma distributed with ntdof / 2 degrees of freedom and scale T
+double BussiThermostat::drawTargetEnergy(uint64_t timestep)
+    {
     std::seed_seq seq {(uint64_t)m_sysdef->getSeed(), timestep, (uint64_t)0x42757373u};
     std::mt19937_64 rng(seq);
-    std::gamma_distribution<double> gamma(ntdof / 2.0, m_T);
-    return {std::sqrt(gamma(rng) / m_thermo->getTranslationalKineticEnergy()), 1.0};
+    std::gamma_distribution<double> gamma(m_thermo->getTranslationalDOF() / 2.0, m_T);
+    return gamma(rng);
+    }
+
+// The same factor without the host waiting for the kinetic energy: the sums are queued, the random target energy does
+// not depend on them, and the first half step divides the two on the device.  A kinetic energy of zero is reported from
+// the latest sums that have arrived, so the error of the reference comes a time step late at most.
+bool BussiThermostat::getDeferredFactorOne(uint64_t timestep, Scalar deltaT, const double*& d_ke, double& gamma)
+    {
+    if (m_thermo->reducesOverRanks() || std::getenv("HOOMD_AMD_NO_DEFERRED_THERMOSTAT"))
+        return false;
+    m_thermo->computeAsync(timestep);
+    if (m_thermo->getTranslationalDOF() != 0 && m_thermo->peekLatestKineticEnergy() == 0)
+        throw std::runtime_error("Bussi thermostat requires non-zero initial temperatures");
+    gamma = drawTargetEnergy(timestep);
+    d_ke = m_thermo->deviceValues();
+    return true;
     }
 
     } // namespace hoomd_amd

@@ -1315,6 +1315,30 @@ class ComputeThermoGPU : public Compute
     public:
     ComputeThermoGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ParticleGroup> group);
     void compute(uint64_t timestep) override;
+    //! Queues the sums of `timestep` (unless they are this time step's already) and returns without waiting for them:
+    //! they stay on the device (deviceValues()) and reach the host when compute() of the same time step asks.
+    void computeAsync(uint64_t timestep);
+    //! The sums of `timestep` are already queued by somebody else with the arguments of fillArgs() (the second half
+    //! step that computes them in its own pass): nothing is launched for that time step any more.
+    void adoptQueuedValues(uint64_t timestep);
+    void fillArgs(hmd_thermo_args_t& a);
+    const double* deviceValues() const
+        {
+        return m_out.get();
+        }
+    //! kinetic energy of the latest sums that have finished on the device (never waits; 1 before the first)
+    double peekLatestKineticEnergy()
+        {
+        return *reinterpret_cast<volatile double*>(m_host_copy.get());
+        }
+    bool reducesOverRanks() const
+        {
+        return (bool)m_allreduce_sum;
+        }
+    std::shared_ptr<ParticleGroup> getGroup() const
+        {
+        return m_group;
+        }
     Scalar getTranslationalKineticEnergy() const
         {
         return m_vals[0];
@@ -1352,6 +1376,10 @@ class ComputeThermoGPU : public Compute
     DeviceArray<Scalar> m_out;
     DeviceArray<unsigned char> m_scratch;
     std::array<Scalar, 8> m_vals {{0, 0, 0, 0, 0, 0, 0, 0}};
+    PinnedWords m_host_copy {16}; // eight doubles the final reduction also stores to (peekLatestKineticEnergy)
+    bool m_host_stale = false;    // the device holds sums the host has not fetched
+    void launch();
+    void fetch();
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1374,6 +1402,16 @@ class Thermostat
         return {1.0, 1.0};
         }
     virtual void advanceThermostat(uint64_t timestep, Scalar deltaT) { }
+    //! A factor for the first half step of the form sqrt(gamma / kinetic energy) that the device evaluates, with the
+    //! kinetic energy left at d_ke by sums that are queued but not waited for; false = ask getRescalingFactorsOne.
+    virtual bool getDeferredFactorOne(uint64_t timestep, Scalar deltaT, const double*& d_ke, double& gamma)
+        {
+        return false;
+        }
+    std::shared_ptr<ComputeThermoGPU> getThermo() const
+        {
+        return m_thermo;
+        }
     void setT(Scalar T)
         {
         m_T = T;
@@ -1412,6 +1450,10 @@ class BussiThermostat : public Thermostat
     public:
     using Thermostat::Thermostat;
     std::array<Scalar, 2> getRescalingFactorsOne(uint64_t timestep, Scalar deltaT) override;
+    bool getDeferredFactorOne(uint64_t timestep, Scalar deltaT, const double*& d_ke, double& gamma) override;
+
+    private:
+    double drawTargetEnergy(uint64_t timestep);
     };
 
 // ---------------------------------------------------------------------------------------------
@@ -1435,6 +1477,12 @@ class IntegrationMethodTwoStep
         {
         m_deltaT = dt;
         }
+    //! whether the second half step may also take sums over the velocities it leaves (nothing touches the particles
+    //! before the next first half step)
+    void setSumsRide(bool v)
+        {
+        m_sums_ride = v;
+        }
     std::shared_ptr<ParticleGroup> getGroup() const
         {
         return m_group;
@@ -1447,6 +1495,7 @@ class IntegrationMethodTwoStep
     std::shared_ptr<ParticleData> m_pdata;
     std::shared_ptr<ParticleGroup> m_group;
     Scalar m_deltaT = 0;
+    bool m_sums_ride = false;
     };
 
 class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
@@ -1468,6 +1517,15 @@ class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
         {
         m_thermostat = t;
         }
+    //! second half steps that took the thermostat's sums along / first half steps whose factor the device worked out
+    uint64_t getNumStepsWithSums() const
+        {
+        return m_n_with_sums;
+        }
+    uint64_t getNumDeferredFactors() const
+        {
+        return m_n_deferred;
+        }
     //! maximum displacement per step; negative disables (hoomd/md/TwoStepConstantVolume.h:57-67)
     void setLimit(Scalar l)
         {
@@ -1481,6 +1539,7 @@ class TwoStepConstantVolumeGPU : public IntegrationMethodTwoStep
     private:
     std::shared_ptr<Thermostat> m_thermostat;
     Scalar m_limit = -1;
+    uint64_t m_n_with_sums = 0, m_n_deferred = 0;
     };
 
 // ---------------------------------------------------------------------------------------------

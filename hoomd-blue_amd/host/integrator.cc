@@ -28,9 +28,17 @@ void TwoStepConstantVolumeGPU::integrateStepOne(uint64_t timestep)
     {
     if (m_group->getNumMembersGlobal() == 0)
         throw std::runtime_error("Empty integration group.");
-    const auto rescale = m_thermostat ? m_thermostat->getRescalingFactorsOne(timestep, m_deltaT) : std::array<Scalar, 2> {1., 1.};
+    // (a factor the device can work out from sums that are only queued spares the host the wait for them)
+    const double* d_ke = nullptr;
+    double gamma = 0.0;
+    const bool deferred = m_thermostat && m_thermostat->getDeferredFactorOne(timestep, m_deltaT, d_ke, gamma);
+    const auto rescale = m_thermostat && !deferred ? m_thermostat->getRescalingFactorsOne(timestep, m_deltaT) : std::array<Scalar, 2> {1., 1.};
     hmd_step_one_args_t a;
     std::memset(&a, 0, sizeof(a));
+    a.d_rescale_ke = d_ke;
+    a.rescale_gamma = gamma;
+    if (deferred)
+        m_n_deferred++;
     a.d_pos = m_pdata->pos();
     a.d_vel = m_pdata->vel();
     a.d_accel = m_pdata->accel();
@@ -89,6 +97,23 @@ void TwoStepConstantVolumeGPU::integrateStepTwo(uint64_t timestep)
         a.d_net_force = m_pdata->netForceForIntegration();
     a.deltaT = m_deltaT;
     a.rescale_factor = rescale[0];
+    // With a thermostat that reads the kinetic energy of the next time step from the device, the sums are taken in this
+    // pass (the velocities it leaves are the ones they are over), when nothing touches the particles in between.
+    if (m_thermostat && m_sums_ride && !f2)
+        {
+        auto thermo = m_thermostat->getThermo();
+        hmd_thermo_args_t th;
+        thermo->fillArgs(th);
+        if (!thermo->reducesOverRanks() && !th.d_net_virial && th.d_net_force == a.d_net_force && th.d_group_members == a.d_group_members
+            && th.group_size == a.group_size && !std::getenv("HOOMD_AMD_NO_DEFERRED_THERMOSTAT"))
+            {
+            ScopedKernelTimer t("step_two_thermo");
+            abiCheck(hmd_nvt_rescale_step_two_thermo(&a, &th, nullptr), "hmd_nvt_rescale_step_two_thermo");
+            thermo->adoptQueuedValues(timestep + 1);
+            m_n_with_sums++;
+            return;
+            }
+        }
     ScopedKernelTimer t("step_two");
     abiCheck(hmd_nvt_rescale_step_two(&a, nullptr), "hmd_nvt_rescale_step_two");
     }
@@ -367,7 +392,13 @@ void IntegratorTwoStep::update(uint64_t timestep)
         }
     else
         for (auto it = m_methods.rbegin(); it != m_methods.rend(); ++it)
+            {
+            // (the run loop has promised that the next update() follows with nothing in between: a thermostat's sums
+            // of the next time step may be taken in this pass)
+            (*it)->setSumsRide(m_lookahead && m_methods.size() == 1);
             (*it)->integrateStepTwo(timestep);
+            (*it)->setSumsRide(false);
+            }
     }
 
 void IntegratorTwoStep::flush()

@@ -466,6 +466,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
     py::class_<TwoStepConstantVolumeGPU, IntegrationMethodTwoStep, std::shared_ptr<TwoStepConstantVolumeGPU>>(m, "TwoStepConstantVolumeGPU")
         .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<ParticleGroup>, std::shared_ptr<Thermostat>>())
         .def("setThermostat", &TwoStepConstantVolumeGPU::setThermostat)
+        .def_property_readonly("num_steps_with_sums", &TwoStepConstantVolumeGPU::getNumStepsWithSums)
+        .def_property_readonly("num_deferred_factors", &TwoStepConstantVolumeGPU::getNumDeferredFactors)
         .def_property("maximum_displacement", &TwoStepConstantVolumeGPU::getLimit, &TwoStepConstantVolumeGPU::setLimit)
         .def("integrateStepOne", &TwoStepConstantVolumeGPU::integrateStepOne)
         .def("integrateStepTwo", &TwoStepConstantVolumeGPU::integrateStepTwo)

@@ -458,6 +458,13 @@ typedef struct
     double deltaT;
     int use_limit;
     double maximum_displacement;
+    /* Optional: the factor is sqrt(rescale_gamma / *d_rescale_ke), evaluated on the device, and rescale_factor is
+       ignored.  For a thermostat whose factor is a random target energy over the kinetic energy of this very time step
+       (BussiThermostat, hoomd/md/Thermostat.h:348-371): the kinetic energy stays where hmd_compute_thermo left it
+       (d_out[0]) and the host does not wait for it.  Division and square root are the correctly rounded ones, so the
+       factor has the bits the host would compute from a copy of the same sum. */
+    const double* d_rescale_ke;
+    double rescale_gamma;
     } hmd_step_one_args_t;
 int hmd_nvt_rescale_step_one(const hmd_step_one_args_t* args, void* stream);
 
@@ -535,8 +542,18 @@ typedef struct
     size_t net_virial_pitch;
     const unsigned int* d_group_members; /* NULL = identity */
     unsigned int group_size;
+    /* optional: the device's view of eight doubles of mapped pinned host memory that receive the same values (a host
+       that does not wait for the sums can still look at the latest finished ones) */
+    double* d_out_host;
     } hmd_thermo_args_t;
 int hmd_compute_thermo(const hmd_thermo_args_t* args, void* stream);
+/* gpu_nvt_rescale_step_two (hoomd/md/TwoStepConstantVolumeGPU.cu:215-260) followed by the thermo sums of the new
+   velocities (hoomd/md/ComputeThermoGPU.cu:46-130,326-520) in ONE pass over the particles: with a thermostat the sums
+   of the finished step are needed before the next first half step, and the velocities are in registers here.
+   Bit-identical to hmd_nvt_rescale_step_two followed by hmd_compute_thermo (same tree of partial sums).  `thermo`
+   must name the same group, velocities and net force as `two`, without virial (d_net_virial NULL) and without a
+   second force array; HMD_ERR_UNSUPPORTED otherwise. */
+int hmd_nvt_rescale_step_two_thermo(const hmd_step_two_args_t* two, const hmd_thermo_args_t* thermo, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Particle reordering by cell (data locality for the neighbor gathers).  Stands in for the

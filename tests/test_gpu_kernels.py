@@ -550,6 +550,72 @@ def test_half_steps_add_two_force_arrays_like_the_net_force_pass(K, A):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("grouped", [False, True])
+def test_second_half_step_takes_the_thermo_sums_along(K, A, grouped):
+    """hmd_nvt_rescale_step_two_thermo: the second half step and the sums over the velocities it leaves in one pass,
+    bit-identical to hmd_nvt_rescale_step_two followed by hmd_compute_thermo (same tree of partial sums); what the
+    pass cannot take along is declined."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    N = 300_001  # more than one trip of the grid-stride loop, a ragged last one
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    nf = np.concatenate([rng.normal(0, 7.0, (N, 3)), rng.normal(-3, 1, (N, 1))], 1)
+    group = torch.from_numpy(np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32)).cuda() if grouped else None
+    tf = torch.from_numpy(nf).cuda()
+    va, vb = torch.from_numpy(vel.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+    aa, ab = torch.zeros((N, 3), dtype=torch.float64, device="cuda"), torch.zeros((N, 3), dtype=torch.float64, device="cuda")
+    K.step_two(va, aa, tf, 0.005, rescale=0.97, group=group)
+    sums_a = K.thermo(va, tf, group=group)
+    sums_b = K.step_two_thermo(vb, ab, tf, 0.005, rescale=0.97, group=group).cpu().numpy()
+    assert np.array_equal(va.cpu().numpy(), vb.cpu().numpy()) and np.array_equal(aa.cpu().numpy(), ab.cpu().numpy())
+    assert np.array_equal(sums_a, sums_b) and sums_b[0] > 0
+    # sums over other arrays than the half step's, or with virials: HMD_ERR_UNSUPPORTED
+    s, t = A.StepTwoArgs(), A.ThermoArgs()
+    s.d_vel, s.d_accel, s.d_net_force, s.group_size, s.deltaT, s.rescale_factor = K.ptr(vb), K.ptr(ab), K.ptr(tf), N, 0.005, 1.0
+    out, scratch = torch.zeros(8, dtype=torch.float64, device="cuda"), torch.zeros(A.lib.hmd_thermo_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    t.d_out, t.d_scratch, t.d_vel, t.d_net_force, t.group_size = K.ptr(out), K.ptr(scratch), K.ptr(va), K.ptr(tf), N
+    assert A.lib.hmd_nvt_rescale_step_two_thermo(C.byref(s), C.byref(t), None) == A.ERR_UNSUPPORTED
+    t.d_vel, t.d_net_virial = K.ptr(vb), K.ptr(scratch)
+    assert A.lib.hmd_nvt_rescale_step_two_thermo(C.byref(s), C.byref(t), None) == A.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert np.array_equal(vb.cpu().numpy(), va.cpu().numpy())  # nothing ran
+
+
+def test_first_half_step_reads_its_factor_from_the_device(K, A):
+    """d_rescale_ke: the factor sqrt(rescale_gamma / kinetic energy) is worked out by the kernel from the sum the thermo
+    pass left on the device; the same bits as with the factor the host computes from a copy of that sum, in the first
+    half step alone and joined with the distance check."""
+    xyz, typ, L = liquid(10, seed=16)
+    N = len(xyz)
+    rng = np.random.default_rng(5)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    vel = np.concatenate([rng.normal(0, 1.3, (N, 3)), rng.uniform(0.5, 2.0, (N, 1))], 1)
+    accel = rng.normal(0, 5.0, (N, 3))
+    image = np.zeros((N, 3), dtype=np.int32)
+    nf = torch.zeros((N, 4), dtype=torch.float64, device="cuda")
+    sums = torch.from_numpy(K.thermo(torch.from_numpy(vel).cuda(), nf)).cuda()
+    gamma = 1.2345678901234567 * 1.5 * N
+    factor = float(np.sqrt(np.float64(gamma) / np.float64(sums[0].item())))
+    assert 0.5 < factor < 2.0
+    out = []
+    for kw in (dict(rescale=factor), dict(rescale=123.0, rescale_ke=sums, rescale_gamma=gamma)):
+        tp, tv, ta, ti = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image))
+        K.step_one(tp, tv, ta, ti, gbox, 0.005, **kw)
+        out.append((tp.cpu().numpy(), tv.cpu().numpy(), ti.cpu().numpy()))
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+    out2 = []
+    for kw in (dict(rescale_one=factor), dict(rescale_one=123.0, rescale_ke=sums, rescale_gamma=gamma)):
+        tp, tv, ta, ti = (torch.from_numpy(x.copy()).cuda() for x in (pos, vel, accel, image))
+        last = torch.from_numpy(pos.copy()).cuda()
+        flag = K.fused_step(tp, tv, ta, ti, nf, gbox, 0.005, last_pos=last, rcut_max=[2.5], r_buff=0.4, step_two=False, **kw)
+        out2.append((tp.cpu().numpy(), tv.cpu().numpy(), ti.cpu().numpy(), np.array(flag[0])))
+    for x, y in zip(*out2):
+        assert np.array_equal(x, y)
+    assert np.array_equal(out[0][0], out2[0][0])
+
+
 def test_first_half_step_with_check_and_slot_copy_matches_the_separate_drivers(K, A):
     """hmd_nvt_rescale_step_one_check: step one with a thermostat's rescaling factor + distance check + slot-ordered
     position copy in one kernel, bit-identical to the drivers run one after the other."""

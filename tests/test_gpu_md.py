@@ -315,6 +315,36 @@ def test_thermostats(hoomd):
         sim.run(10)
 
 
+def test_bussi_factor_worked_out_on_the_device_changes_no_bit(hoomd, monkeypatch):
+    """With the Bussi thermostat the kinetic energy stays on the device: the second half step takes the sums along, the
+    first half step of the next time step divides the random target energy by them, and the host never waits.  The same
+    arithmetic as the path through the host (HOOMD_AMD_NO_DEFERRED_THERMOSTAT): trajectories and logged energies agree
+    bit for bit, through rebuilds and runs cut into pieces."""
+    snap = jittered_lattice_snapshot(hoomd, 14, jitter=0.05, kT=0.8, seed=3)
+    out = []
+    for host_path in (False, True):
+        if host_path:
+            monkeypatch.setenv("HOOMD_AMD_NO_DEFERRED_THERMOSTAT", "1")
+        else:
+            monkeypatch.delenv("HOOMD_AMD_NO_DEFERRED_THERMOSTAT", raising=False)
+        sim, cell, lj, method = make_sim(hoomd, snap, thermostat=hoomd.md.methods.thermostats.Bussi(kT=1.6))
+        cell.deterministic = True  # (the order of a cell's members, and with it the order of the force sums, is the same in both runs)
+        th = hoomd.md.compute.ThermodynamicProperties(hoomd.filter.All())
+        sim.operations.computes.append(th)
+        sim.run(41)
+        ke_mid = th.kinetic_energy
+        sim.run(1)
+        sim.run(30)
+        s = sim.state.get_snapshot()
+        m = method._cpp_obj
+        assert (m.num_deferred_factors == 0 and m.num_steps_with_sums == 0) if host_path else (m.num_deferred_factors == 72 and m.num_steps_with_sums >= 65)
+        out.append((s.particles.position.copy(), s.particles.velocity.copy(), s.particles.image.copy(), lj.forces.copy(), np.array(ke_mid),
+                    np.array(th.kinetic_energy), np.array(th.potential_energy), cell.num_builds))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    assert out[0][7] >= 4 and abs(2 * out[0][5] / (3 * snap.particles.N - 3) - 1.6) < 0.15
+
+
 def test_api_errors_and_state(hoomd):
     snap = two_particle_snapshot(hoomd, d=1.2, types=("A", "B"))
     sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=1)
