@@ -82,6 +82,7 @@ template<int HALF> __device__ __forceinline__ unsigned int pft_slot_bytes(unsign
 constexpr int PFT_THREADS = 256;              // 4 waves share one staged region
 constexpr int PFT_T = 4;                      // lanes per home particle: 64 / PFT_T = TL_GROUP home particles per wave
 constexpr int PFT_PRE = 6;                    // pieces of every row (96 entries) fetched one group ahead
+constexpr int PFT_TAIL = 2;                   // further pieces fetched at the start of a group by the lanes whose rows are that long
 static_assert(64 / PFT_T == (int)TL_GROUP && PFT_T * 4 == (int)TL_PIECE, "a wave reads one piece of each of its sixteen rows per trip");
 constexpr int PFT_WAVES = PFT_THREADS / 64;
 constexpr int PFT_TRIPS = 4;
@@ -743,6 +744,16 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
 #else
         constexpr bool PIPELINED = (SHIFT == 0 && !VIRIAL && !TWO_TYPES && !BATCH4);
 #endif
+#ifndef HMD_PFT_NO_TAIL_PREFETCH
+        uint2 tail[PFT_TAIL];
+#pragma unroll
+        for (int t = 0; t < PFT_TAIL; t++)
+            {
+            tail[t] = make_uint2(0u, 0u);
+            if ((unsigned int)(TL_PIECE * (PFT_PRE + t)) + 4u * s4 < nn)
+                tail[t] = (rows + (size_t)grp * P * 64)[(PFT_PRE + t) * 64u];
+            }
+#endif
         quad qa;
         if (PIPELINED)
             {
@@ -773,11 +784,27 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
                     pairs(qa);
                     }
             }
-        // rows longer than PFT_PRE pieces
-        if (__any((unsigned int)(TL_PIECE * PFT_PRE) < nn))
+        // rows longer than PFT_PRE pieces: the next PFT_TAIL pieces were asked for before the arithmetic above (only by
+        // the lanes whose rows reach that far), so they have arrived by now; what lies beyond is read on the spot
+#ifndef HMD_PFT_NO_TAIL_PREFETCH
+#pragma unroll
+        for (int t = 0; t < PFT_TAIL; t++)
+            {
+            const bool more = (unsigned int)(TL_PIECE * (PFT_PRE + t)) + 4u * s4 < nn;
+            if (__any(more) && more)
+                {
+                read_quad(tail[t], qa);
+                pairs(qa);
+                }
+            }
+        constexpr int tail_done = PFT_PRE + PFT_TAIL;
+#else
+        constexpr int tail_done = PFT_PRE;
+#endif
+        if (__any((unsigned int)(TL_PIECE * tail_done) < nn))
             {
             const uint2* rp = rows + (size_t)grp * P * 64;
-            for (unsigned int q = PFT_PRE; q < P; q++)
+            for (unsigned int q = tail_done; q < P; q++)
                 {
                 const bool more = TL_PIECE * q + 4u * s4 < nn;
                 if (!__any(more))

@@ -179,6 +179,32 @@ def test_tile_lj_forces_match_oracle(K, A, shift_mode, ntypes):
     assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
 
 
+@pytest.mark.parametrize("ntypes", [1, 2, 3])
+def test_tile_forces_with_densely_filled_cells(K, A, ntypes):
+    """More than 32 members in most cells (density 1.3: the staging takes the members past the 32nd of a cell in extra
+    trips) and rows longer than the pieces fetched a group ahead: forces, energies and virials against the oracle."""
+    xyz, typ, L = liquid(16, rho=1.3, jitter=0.08, ntypes=ntypes, seed=40 + ntypes)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    sig = [[1.0, 0.8, 0.9], [0.8, 0.88, 0.85], [0.9, 0.85, 0.95]]
+    eps = [[1.0, 1.5, 1.2], [1.5, 0.5, 0.7], [1.2, 0.7, 0.9]]
+    r_cut = [[2.5 * sig[i][j] for j in range(ntypes)] for i in range(ntypes)]
+    params = [orc.lj_params(eps[i][j], sig[i][j]) for i in range(ntypes) for j in range(ntypes)]
+    rcutsq = np.square(r_cut)
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, cl, _ = tile_nlist(K, A, pos_t, N, gbox, obox, r_cut, 0.4)
+    assert (cl["cell_size"].cpu().numpy() > 32).mean() > 0.3
+    assert tl["n_neigh"].cpu().numpy().view(np.uint32)[:N].max() > (128 if ntypes == 1 else 96)  # (longer than the pieces fetched a group ahead)
+    half = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=False)
+    F_ref, V_ref = orc.pair_forces(orc.EV_LJ, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], params, rcutsq,
+                                   np.zeros_like(rcutsq), shift_mode=0, third_law=True, compute_virial=True)
+    F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, np.zeros_like(rcutsq), shift_mode=0, compute_virial=True)
+    F2, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, np.zeros_like(rcutsq), shift_mode=0, compute_virial=False)
+    assert _rel_err(F.cpu().numpy(), F_ref) < F_RTOL * 1e-4 and _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
+    assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
+
+
 def test_tile_path_limits_are_reported(K, A):
     gbox, _ = boxes(A, 5.0)
     xyz = (np.random.default_rng(1).random((50, 3)) - 0.5) * 5.0
