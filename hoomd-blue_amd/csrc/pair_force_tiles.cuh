@@ -79,14 +79,14 @@ template<int HALF> __device__ __forceinline__ unsigned int pft_slot_bytes(unsign
     return r;
     }
 
-constexpr int PFT_THREADS = 256;              // 4 waves share one staged region
+constexpr int PFT_THREADS = 256;              // 4 waves share one staged region (8 where only two regions fit a CU's LDS)
 constexpr int PFT_T = 4;                      // lanes per home particle: 64 / PFT_T = TL_GROUP home particles per wave
 constexpr int PFT_PRE = 6;                    // pieces of every row (96 entries) fetched one group ahead
 constexpr int PFT_TAIL = 2;                   // further pieces fetched at the start of a group by the lanes whose rows are that long
 static_assert(64 / PFT_T == (int)TL_GROUP && PFT_T * 4 == (int)TL_PIECE, "a wave reads one piece of each of its sixteen rows per trip");
 constexpr int PFT_WAVES = PFT_THREADS / 64;
 constexpr int PFT_TRIPS = 4;
-static_assert(TR_X == 4 && TR_Y == 4 && TR_Z == 4 && PFT_WAVES == 4 && TL_NH == 8, "staging maps (lane / 16, wave, trip) to the cells of a 4x4x4 region");
+static_assert(TR_X == 4 && TR_Y == 4 && TR_Z == 4 && PFT_WAVES == 4 && TL_NH == 8, "staging maps (lane / 16, wave % 4, trip) to the cells of a 4x4x4 region");
 
 // The integration pass that may ride on the kernel, in the form the kernel carries it: an orthorhombic box periodic
 // in all three directions that has not changed since the neighbor list was built, no velocity rescaling -- the case
@@ -308,8 +308,10 @@ __device__ __forceinline__ pft_axis pft_axis_cell(int c, int dim, bool periodic)
 // and the slot-ordered copy (step_body.cuh) -- the force never makes the round trip through memory to a separate
 // pass, and a time step is this one kernel.  The new positions go to the particle array, which this kernel does not
 // read, and to a second slot-ordered buffer (st.d_cpos must not be g.d_cpos: other workgroups are still staging from it).
-template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false, bool STEP = false>
-__global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
+// WAVES: 4, or 8 for regions so large that only two workgroups fit the LDS of a CU -- the same sixteen waves per CU then
+// (the waves of the second half take the upper two layers of the region in the staging phase).
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false, bool STEP = false, int WAVES = PFT_WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params,
                             pft_launch_t lp, pft_step_t st)
     {
@@ -421,36 +423,43 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
 
     // ---- staging, first half: every load of the region is issued before anything is known about the
     // cells' populations.  Sixteen lanes take one region cell: rx = lane / 16, ry = wave, rz = trip, so a wave
-    // covers a 4x1x4 slab of the region in four trips; slots k16 and k16 + 16 of every cell are fetched
+    // covers a 4x1x4 slab of the region in four trips (of eight waves, wave and wave + 4 share a slab, two trips each); slots k16 and k16 + 16 of every cell are fetched
     // unconditionally (slots past a cell's population hold stale data that is never used), and with them the
     // row info of the home cells' members.  The cell sizes arrive in the same round trip (wave 0 below):
     // staging costs one memory latency, not three.
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    static_assert(WAVES == 4 || WAVES == 8, "four or eight waves");
+    constexpr int TRIPS = 4 * PFT_WAVES / WAVES;
     const unsigned int rx = lane / 16, k16 = lane % 16;
+    const unsigned int ry = WAVES == 4 ? wave : wave % 4u;
+    const int u0 = WAVES == 4 ? 0 : 2 * (int)(wave / 4u); // first layer of the region this wave stages
     const unsigned int cellNmax = g.cli.w;
     const pft_axis ax = pft_axis_cell(cx0 - 1 + (int)rx, dimx, a.box.periodic[0]);
-    const pft_axis ay = pft_axis_cell(cy0 - 1 + (int)wave, dimy, a.box.periodic[1]);
-    const bool home_xy = (rx == 1 || rx == 2) && (wave == 1 || wave == 2) && cx0 + (int)rx - 1 < dimx && cy0 + (int)wave - 1 < dimy;
-    pft_pos pA[PFT_TRIPS], pB[PFT_TRIPS];
+    const pft_axis ay = pft_axis_cell(cy0 - 1 + (int)ry, dimy, a.box.periodic[1]);
+    const bool home_xy = (rx == 1 || rx == 2) && (ry == 1 || ry == 2) && cx0 + (int)rx - 1 < dimx && cy0 + (int)ry - 1 < dimy;
+    // (layers 1 and 2 hold the home cells: with four trips per wave their row info goes to mA[0], mA[1]; with two trips
+    // a wave meets one of them, mA[0])
+    pft_pos pA[TRIPS], pB[TRIPS];
     uint2 mA[2], mB[2];
-    pft_axis az[PFT_TRIPS];
+    pft_axis az[TRIPS];
         {
         // byte offsets fit 32 bits (checked by the launcher): one scalar base plus a 32-bit lane offset per load
         const unsigned int oA = min(k16, cellNmax - 1u) * 32u, oB = min(k16 + 16u, cellNmax - 1u) * 32u;
         const char* cpos = reinterpret_cast<const char*>(g.d_cpos);
         const char* meta = reinterpret_cast<const char*>(g.d_slot_meta);
 #pragma unroll
-        for (int u = 0; u < PFT_TRIPS; u++)
+        for (int t = 0; t < TRIPS; t++)
             {
-            az[u] = pft_axis_cell(cz0 - 1 + u, dimz, a.box.periodic[2]);
-            const bool valid = ax.valid && ay.valid && az[u].valid;
-            const unsigned int base = valid ? (unsigned int)((az[u].c * dimy + ay.c) * dimx + ax.c) * cellNmax * 32u : 0u;
-            pA[u] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oA)));
-            pB[u] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oB)));
+            const int u = u0 + t;
+            az[t] = pft_axis_cell(cz0 - 1 + u, dimz, a.box.periodic[2]);
+            const bool valid = ax.valid && ay.valid && az[t].valid;
+            const unsigned int base = valid ? (unsigned int)((az[t].c * dimy + ay.c) * dimx + ax.c) * cellNmax * 32u : 0u;
+            pA[t] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oA)));
+            pB[t] = pft_ld_pos<!SINGLE_TYPE>(reinterpret_cast<const hmd_scalar4*>(cpos + (base + oB)));
             if ((u == 1 || u == 2) && home_xy)
                 {
-                mA[u - 1] = *reinterpret_cast<const uint2*>(meta + ((base + oA) >> 1));
-                mB[u - 1] = *reinterpret_cast<const uint2*>(meta + ((base + oB) >> 1));
+                mA[WAVES == 4 ? t - 1 : 0] = *reinterpret_cast<const uint2*>(meta + ((base + oA) >> 1));
+                mB[WAVES == 4 ? t - 1 : 0] = *reinterpret_cast<const uint2*>(meta + ((base + oB) >> 1));
                 }
             }
         }
@@ -488,7 +497,7 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             ronsq0 = a.d_ronsq[0];
         }
     else
-        for (unsigned int t = threadIdx.x; t < np; t += PFT_THREADS)
+        for (unsigned int t = threadIdx.x; t < np; t += 64u * WAVES)
             {
             s_params[t] = d_params[t];
             s_rcutsq[t] = a.d_rcutsq[t];
@@ -510,16 +519,18 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
     // cell-list slot): image = rint(centre of the region cell - position) in fractional coordinates
     // (hoomd/BoxDim.h:260-268, 391-458). ----
 #pragma unroll
-    for (int u = 0; u < PFT_TRIPS; u++)
+    for (int t = 0; t < TRIPS; t++)
         {
-        const unsigned int rc = (unsigned int)tile_rc((int)rx, (int)wave, u);
+        const int u = u0 + t;
+        const int mi = WAVES == 4 ? t - 1 : 0;
+        const unsigned int rc = (unsigned int)tile_rc((int)rx, (int)ry, u);
         const unsigned int first = T.off[rc], size = T.off[rc + 1] - first;
         if (__builtin_amdgcn_readfirstlane(__ballot(size != 0) == 0))
             continue;
-        const bool edge = ax.edge || ay.edge || az[u].edge;
+        const bool edge = ax.edge || ay.edge || az[t].edge;
         // centre of the region cell in fractional coordinates, from its UNWRAPPED grid coordinate
         const double fcx = ((double)(cx0 - 1 + (int)rx) + 0.5) * lp.inv_dim[0];
-        const double fcy = ((double)(cy0 - 1 + (int)wave) + 0.5) * lp.inv_dim[1];
+        const double fcy = ((double)(cy0 - 1 + (int)ry) + 0.5) * lp.inv_dim[1];
         const double fcz = ((double)(cz0 - 1 + u) + 0.5) * lp.inv_dim[2];
         auto place = [&](const pft_pos& pp, unsigned int k)
         {
@@ -540,25 +551,25 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
             txyz[v + 64] = z;
         };
         if (k16 < size)
-            place(pA[u], k16);
+            place(pA[t], k16);
         if (k16 + 16u < size)
-            place(pB[u], k16 + 16u);
+            place(pB[t], k16 + 16u);
         // members of a home cell of this block get their entry of the home table
         const bool home_cell = (u == 1 || u == 2) && home_xy && cz0 + u - 1 < dimz;
         unsigned int hfirst = 0;
         if (u == 1 || u == 2)
             {
             if (home_cell)
-                hfirst = T.hcum[((u - 1) * TB_Y + (wave - 1)) * TB_X + (rx - 1)];
+                hfirst = T.hcum[((u - 1) * TB_Y + (ry - 1)) * TB_X + (rx - 1)];
             if (home_cell && k16 < size)
-                s_home[hfirst + k16] = pft_home(mA[u - 1].x, mA[u - 1].y, tile_slot(first + k16) | (SINGLE_TYPE ? 0u : pA[u].t << TL_TYPE_SHIFT));
+                s_home[hfirst + k16] = pft_home(mA[mi].x, mA[mi].y, tile_slot(first + k16) | (SINGLE_TYPE ? 0u : pA[t].t << TL_TYPE_SHIFT));
             if (home_cell && k16 + 16u < size)
-                s_home[hfirst + k16 + 16u] = pft_home(mB[u - 1].x, mB[u - 1].y, tile_slot(first + k16 + 16u) | (SINGLE_TYPE ? 0u : pB[u].t << TL_TYPE_SHIFT));
+                s_home[hfirst + k16 + 16u] = pft_home(mB[mi].x, mB[mi].y, tile_slot(first + k16 + 16u) | (SINGLE_TYPE ? 0u : pB[t].t << TL_TYPE_SHIFT));
             }
         // cells with more than 32 members (uncommon): the rest, one dependent load per trip
         if (__builtin_amdgcn_readfirstlane(__ballot(size > 32u) != 0))
             {
-            const unsigned int base = (unsigned int)((az[u].c * dimy + ay.c) * dimx + ax.c) * cellNmax;
+            const unsigned int base = (unsigned int)((az[t].c * dimy + ay.c) * dimx + ax.c) * cellNmax;
             for (unsigned int k = k16 + 32u; k < size; k += 16u)
                 {
                 const pft_pos pk = pft_ld_pos<!SINGLE_TYPE>(g.d_cpos + base + k);
@@ -857,16 +868,16 @@ __global__ void __launch_bounds__(PFT_THREADS, 4) // four waves per SIMD (128 re
         fetch(grp, b0);
     while (grp < ngroups)
         {
-        if (grp + PFT_WAVES < ngroups)
-            fetch(grp + PFT_WAVES, b1);
+        if (grp + WAVES < ngroups)
+            fetch(grp + WAVES, b1);
         process(grp, b0);
-        grp += PFT_WAVES;
+        grp += WAVES;
         if (grp >= ngroups)
             break;
-        if (grp + PFT_WAVES < ngroups)
-            fetch(grp + PFT_WAVES, b0);
+        if (grp + WAVES < ngroups)
+            fetch(grp + WAVES, b0);
         process(grp, b1);
-        grp += PFT_WAVES;
+        grp += WAVES;
         if (STEP && (kept & 3u) == 0u)
             flush();
         }
@@ -919,7 +930,13 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
         if (nblocks == 0)
             return HMD_OK; // the window is the whole grid: nothing outside it
         }
-    const dim3 grid(nblocks), block(PFT_THREADS);
+    // Eight waves per workgroup where the region is so large that only two workgroups fit the LDS of a CU (densely
+    // filled cells): the CU then holds sixteen waves as it does with four workgroups of four.  (The kernel with the
+    // integration pass riding on it exists with four waves only.)
+    bool eight = !STEP && 3 * (lds + 1024) > 160 * 1024;
+    if (const char* w = std::getenv("HOOMD_AMD_PFT_WAVES"))
+        eight = !STEP && std::atoi(w) == 8;
+    const dim3 grid(nblocks), block(eight ? 512 : PFT_THREADS);
     pft_launch_t lp;
     lp.nbx = (g.ci.w + TB_X - 1) / TB_X;
     lp.nby = (g.ci.h + TB_Y - 1) / TB_Y;
@@ -930,16 +947,37 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
     lp.inv_dim[2] = 1.0 / (double)g.ci.d;
     if (a.ntypes == 1)
         {
+        if constexpr (!STEP)
+            if (eight)
+                {
+                tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, false, 8>, lds);
+                hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, false, 8>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
+                return hmd_launch_status();
+                }
         tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, STEP>, lds);
         hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, true, false, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
     else if (a.ntypes == 2)
         {
+        if constexpr (!STEP)
+            if (eight)
+                {
+                tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8>, lds);
+                hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
+                return hmd_launch_status();
+                }
         tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, STEP>, lds);
         hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
     else
         {
+        if constexpr (!STEP)
+            if (eight)
+                {
+                tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, false, 8>, lds);
+                hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, false, 8>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
+                return hmd_launch_status();
+                }
         tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, STEP>, lds);
         hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, false, STEP>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
         }
