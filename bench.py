@@ -260,7 +260,7 @@ def main():
     # process, so the figure measured for this configuration is carried in profiles/
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02b_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02c_traffic.json")) as f:
             tr = json.load(f)
         if tr.get("N") == n_local and world == 1:
             traffic = tr["kernels"]["pair_force_tiles_kernel_step" if rider else "pair_force_tiles_kernel"]["hbm_bytes_per_launch"]

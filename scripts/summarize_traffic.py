@@ -9,6 +9,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 out = sys.argv[1]
@@ -29,8 +30,9 @@ write = per_kernel(out + "/write", "WRITE_SIZE")
 
 
 def short(n):
-    # the tile force kernel with the integration pass riding on it (last template argument true) is a row of its own
-    if "pair_force_tiles_kernel" in n and n.split(">(")[0].rstrip().endswith("true"):
+    # the tile force kernel with the integration pass riding on it (template argument STEP, the last but one before the
+    # number of waves) is a row of its own
+    if "pair_force_tiles_kernel" in n and re.search(r"true, \d+>\(", n.replace(" >", ">")):
         return "pair_force_tiles_kernel_step"
     for k in ("pair_force_tiles_kernel", "pair_force_kernel", "nlist_pref_kernel", "nlist_binned_kernel", "tile_block_groups_kernel", "fused_step_kernel", "cell_list_kernel", "step_one_kernel",
               "step_two_kernel", "nlist_check_kernel"):
