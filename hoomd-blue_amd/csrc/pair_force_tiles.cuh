@@ -512,6 +512,23 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
     if (total > cap || total == 0)
         return;
     const unsigned int H = T.hcum[TL_NH];
+    const unsigned int ngroups = (H + TL_GROUP - 1) / TL_GROUP;
+    const unsigned int P = g.row_pieces;
+    // piece p of group j of this block: 64 uint2 (four entries each) at rows[(j * P + p) * 64], lane order
+    const uint2* rows = reinterpret_cast<const uint2*>(d_tile_nlist) + (size_t)grp0 * P * 64 + lane;
+    auto fetch = [&](unsigned int grp, uint2 (&c)[PFT_PRE])
+    {
+        const uint2* rp = rows + (size_t)grp * P * 64;
+#pragma unroll
+        for (int q = 0; q < PFT_PRE; q++)
+            c[q] = rp[min((unsigned int)q, P - 1u) * 64u]; // rows with room for fewer pieces: read the last one again
+    };
+    // the rows of this wave's first group are asked for here, so that they arrive while the region is put in place
+    uint2 b0[PFT_PRE], b1[PFT_PRE];
+#ifndef HMD_PFT_LATE_FIRST_FETCH
+    if (wave < ngroups)
+        fetch(wave, b0);
+#endif
 
     // ---- staging, second half: place what arrived.  Members of cells away from the periodic faces of the box are
     // copied as they are; the others go to the periodic image nearest to their region cell, decided per particle
@@ -600,21 +617,10 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
         return;
 #endif
     const unsigned int s4 = lane % PFT_T, gl = lane / PFT_T;
-    const unsigned int ngroups = (H + TL_GROUP - 1) / TL_GROUP;
     // (STEP) the particle whose finished force this lane keeps for the integration pass, and the wave's count of groups
     double kfx = 0.0, kfy = 0.0, kfz = 0.0;
     unsigned int kidx = 0xffffffffu, kept = 0;
-    const unsigned int P = g.row_pieces;
-    // piece p of group j of this block: 64 uint2 (four entries each) at rows[(j * P + p) * 64], lane order
-    const uint2* rows = reinterpret_cast<const uint2*>(d_tile_nlist) + (size_t)grp0 * P * 64 + lane;
     const unsigned int three = 3u;
-    auto fetch = [&](unsigned int grp, uint2 (&c)[PFT_PRE])
-    {
-        const uint2* rp = rows + (size_t)grp * P * 64;
-#pragma unroll
-        for (int q = 0; q < PFT_PRE; q++)
-            c[q] = rp[min((unsigned int)q, P - 1u) * 64u]; // rows with room for fewer pieces: read the last one again
-    };
     auto process = [&](unsigned int grp, const uint2 (&cur)[PFT_PRE])
     {
         const unsigned int h = grp * TL_GROUP + gl;
@@ -862,10 +868,11 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
             kidx = 0xffffffffu;
             }
     };
-    uint2 b0[PFT_PRE], b1[PFT_PRE];
     unsigned int grp = wave;
+#ifdef HMD_PFT_LATE_FIRST_FETCH
     if (grp < ngroups)
         fetch(grp, b0);
+#endif
     while (grp < ngroups)
         {
         if (grp + WAVES < ngroups)
