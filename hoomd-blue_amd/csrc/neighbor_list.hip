@@ -665,6 +665,15 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         const unsigned int nh = min(n_home - hbase, 64u);
         double hx = 0, hy = 0, hz = 0;
         unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0, htype = 0;
+        // (the start of a home particle's row, the number of its exclusions and the first four of them are fetched here,
+        // one home particle per lane, and handed out by lane reads in the loop below: fetched where they are used, each
+        // was a round trip to memory that the whole wave waited for)
+        constexpr unsigned int NEXR = 4;
+        unsigned int hnex = 0, hex[EXCL ? NEXR : 1];
+        unsigned int hhead_lo = 0, hhead_hi = 0;
+#pragma unroll
+        for (unsigned int o = 0; o < (EXCL ? NEXR : 1u); o++)
+            hex[o] = 0xffffffffu;
         if (lane < nh)
             {
             const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
@@ -676,7 +685,23 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             if (TWO)
                 htype = a.d_cell_type_body[w].x & 1u;
             if (hidx < a.N)
+                {
                 hnmax = a.d_Nmax[htype];
+                if (EXCL)
+                    {
+                    hnex = ex.d_n_ex[hidx];
+#pragma unroll
+                    for (unsigned int o = 0; o < (EXCL ? NEXR : 0u); o++)
+                        if (o < hnex)
+                            hex[o] = ex.d_ex_list[hmd_idx2(ex.exli, hidx, o)];
+                    }
+                if (!TILE)
+                    {
+                    const size_t head = a.d_head_list[hidx];
+                    hhead_lo = (unsigned int)head;
+                    hhead_hi = (unsigned int)(head >> 32);
+                    }
+                }
             }
         // origin of the fp32 coordinates: the slab's first home particle
         const double Ox = rl_d(hx, 0), Oy = rl_d(hy, 0), Oz = rl_d(hz, 0);
@@ -798,6 +823,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 const unsigned int nmax_i = rl_u(hnmax, iu);
                 const unsigned int cnt_old = rl_u(cnt, iu);
                 const unsigned int nmax_w = TILE ? min(nmax_i, tile_row_cap) : nmax_i;
+                const size_t row_head = TILE ? 0 : (((size_t)rl_u(hhead_hi, iu) << 32) | (size_t)rl_u(hhead_lo, iu));
                 // thresholds of this particle's type against candidates of type 0 and 1
                 const unsigned int ti = TWO ? rl_u(htype, iu) : 0u;
                 const unsigned int lo1 = TWO ? (ti ? lo1_tp[1] : lo1_tp[0]) : lo1_tp[0];
@@ -867,15 +893,20 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 // excluded partners, by particle index
                 if (EXCL)
                     {
-                    const unsigned int nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
-                    for (unsigned int o = 0; o < nex_i; o++)
-                        {
-                        const unsigned int e = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+                    const unsigned int nex_i = rl_u(hnex, iu);
+                    auto leave_out = [&](unsigned int e)
+                    {
 #pragma unroll
                         for (int c = 0; c < MAXK; c++)
                             if ((unsigned int)(c * 64) < Tp && (TILE ? cidx[c] : co[c]) == e)
                                 bits &= ~(1u << (nslab - 1u - (unsigned int)c));
-                        }
+                    };
+#pragma unroll
+                    for (unsigned int o = 0; o < (EXCL ? NEXR : 0u); o++)
+                        if (o < nex_i)
+                            leave_out(rl_u(hex[o], iu));
+                    for (unsigned int o = NEXR; o < nex_i; o++)
+                        leave_out(__builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]));
                     }
 
                 // ---- compaction: hits ordered by lane, then slab.  One scan over the wave places every lane's hits. ----
@@ -926,7 +957,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                                     trow[((pos & ~15u) << 4) | (pos & 15u)] = (unsigned short)co[c];
                                     }
                                 else
-                                    a.d_nlist[a.d_head_list[i_idx] + pos] = co[c];
+                                    a.d_nlist[row_head + pos] = co[c];
                                 }
                             }
                         }
@@ -962,7 +993,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     }
                 else
                     {
-                    unsigned int* row = a.d_nlist + a.d_head_list[i_idx];
+                    unsigned int* row = a.d_nlist + row_head;
 #pragma unroll
                     for (unsigned int e0 = 0; e0 < (unsigned int)NL_ROWBUF; e0 += 64)
                         {
@@ -1211,6 +1242,13 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
         const unsigned int nh = min(H - hbase, 64u);
         double hx = 0, hy = 0, hz = 0;
         unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0, hq = 0, hself = 0, hslot = 0;
+        // what the loop over the home particles needs from memory per particle -- the start of its row, the number of its
+        // exclusions and the first four of them -- is fetched here, one home particle per lane, and handed out by lane
+        // reads: fetched where it is used, every one of these was a round trip to memory that the whole wave waited for
+        // (three or more per home particle, most of the kernel's time where cells hold three particles).
+        constexpr unsigned int NEXR = 4;
+        unsigned int hnex = 0, hex[NEXR] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        unsigned int hhead_lo = 0, hhead_hi = 0;
         if (lane < nh)
             {
             const unsigned int hn = hbase + lane;
@@ -1234,7 +1272,23 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
             hz = v.z;
             hidx = hmd_double_as_uint(v.w);
             if (hidx < a.N)
+                {
                 hnmax = a.d_Nmax[0];
+                if (EXCL)
+                    {
+                    hnex = ex.d_n_ex[hidx];
+#pragma unroll
+                    for (unsigned int o = 0; o < NEXR; o++)
+                        if (o < hnex)
+                            hex[o] = ex.d_ex_list[hmd_idx2(ex.exli, hidx, o)];
+                    }
+                if (!TILE)
+                    {
+                    const size_t head = a.d_head_list[hidx];
+                    hhead_lo = (unsigned int)head;
+                    hhead_hi = (unsigned int)(head >> 32);
+                    }
+                }
             }
         const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
 
@@ -1304,15 +1358,20 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
                 bits &= ~(1u << (nslab - 1u - (k_self >> 6)));
             if (EXCL)
                 {
-                const unsigned int nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
-                for (unsigned int o = 0; o < nex_i; o++)
-                    {
-                    const unsigned int e = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+                const unsigned int nex_i = rl_u(hnex, iu);
+                auto leave_out = [&](unsigned int e)
+                {
 #pragma unroll
                     for (int c = 0; c < MAXK; c++)
                         if ((unsigned int)(c * 64) < T && (TILE ? cidx[c] : co[c]) == e)
                             bits &= ~(1u << (nslab - 1u - (unsigned int)c));
-                    }
+                };
+#pragma unroll
+                for (unsigned int o = 0; o < NEXR; o++)
+                    if (o < nex_i)
+                        leave_out(rl_u(hex[o], iu));
+                for (unsigned int o = NEXR; o < nex_i; o++)
+                    leave_out(__builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]));
                 }
 
             // ---- compaction: hits ordered by lane, then slab ----
@@ -1323,7 +1382,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
             const unsigned int h_i = hbase + iu;
             unsigned short* trow16 = TILE ? d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE
                                           : nullptr;
-            unsigned int* irow = TILE ? nullptr : a.d_nlist + a.d_head_list[i_idx];
+            unsigned int* irow = TILE ? nullptr : a.d_nlist + (((size_t)rl_u(hhead_hi, iu) << 32) | (size_t)rl_u(hhead_lo, iu));
             const bool fits = cnt_new <= min(nmax_w, (unsigned int)NL_ROWBUF);
             if (fits)
                 {

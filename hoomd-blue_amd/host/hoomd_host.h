@@ -1265,6 +1265,12 @@ class ForceCompute : public Compute
     Scalar calcEnergySum();
     //! Raise what the kernels could only flag (called with the stream idle, e.g. at the end of a run)
     virtual void checkErrors() { }
+    //! whether compute() may have to wait for the host to learn something from the device first (a neighbor list's
+    //! rebuild decision): forces that never do are launched before those that may, so the device has work meanwhile
+    virtual bool mayWaitForDevice() const
+        {
+        return true;
+        }
 
     protected:
     virtual void computeForces(uint64_t timestep) = 0;
@@ -1290,6 +1296,10 @@ class ForceCompute : public Compute
 class PotentialBondFENEGPU : public ForceCompute
     {
     public:
+    bool mayWaitForDevice() const override
+        {
+        return false;
+        }
     explicit PotentialBondFENEGPU(std::shared_ptr<SystemDefinition> sysdef);
     //! k, r0, epsilon, sigma, delta of a bond type (hoomd/md/EvaluatorBondFENE.h:47-67)
     void setParams(unsigned int type, Scalar k, Scalar r0, Scalar epsilon, Scalar sigma, Scalar delta);

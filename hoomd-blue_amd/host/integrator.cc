@@ -244,8 +244,17 @@ std::array<double, 3> IntegratorTwoStep::computeLinearMomentum()
 void IntegratorTwoStep::computeNetForceGPU(uint64_t timestep)
     {
     m_pdata->setNetForcePair(nullptr, nullptr, nullptr); // (a sum of the previous step's forces nobody asked for)
+    // Forces that only launch their kernel go first (a bond force), those that may wait for the device's rebuild decision
+    // before they can launch (a pair force behind its neighbor list) after them: the device computes bonds while the host
+    // looks at the flag.  The forces still add up in the order they were given (the arrays keep their places below).  Not
+    // under domain decomposition, where the neighbor list's check starts the halo exchange the bond force needs.
+    const bool reorder = !m_sysdef->isDomainDecomposed();
     for (auto& f : m_forces)
-        f->compute(timestep);
+        if (reorder && !f->mayWaitForDevice())
+            f->compute(timestep);
+    for (auto& f : m_forces)
+        if (!reorder || f->mayWaitForDevice())
+            f->compute(timestep);
 
     Scalar ext_e = 0, ext_v[6] = {0, 0, 0, 0, 0, 0};
     for (auto& f : m_forces)
