@@ -229,6 +229,8 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         double hx = 0, hy = 0, hz = 0;
         unsigned int hidx = 0xffffffffu, htype = 0, hbody = HMD_NO_BODY, hnmax = 0, cnt = 0;
         unsigned long long hhead = 0;
+        // (exclusions: their number and the first four per home particle, fetched here, one home particle per lane)
+        unsigned int hnex = 0, hex[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         if (lane < nh)
             {
             const unsigned int w = hmd_idx2(a.cli, hbase + lane, cell);
@@ -247,6 +249,14 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 {
                 hnmax = a.d_Nmax[SINGLE_TYPE ? 0 : htype];
                 hhead = a.d_head_list[hidx];
+                if (ex.d_n_ex)
+                    {
+                    hnex = ex.d_n_ex[hidx];
+#pragma unroll
+                    for (unsigned int o = 0; o < 4; o++)
+                        if (o < hnex)
+                            hex[o] = ex.d_ex_list[hmd_idx2(ex.exli, hidx, o)];
+                    }
                 }
             }
 
@@ -331,11 +341,10 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 unsigned int nex_i = 0, ex_r[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
                 if (ex.d_n_ex)
                     {
-                    nex_i = __builtin_amdgcn_readfirstlane(ex.d_n_ex[i_idx]);
+                    nex_i = rl_u(hnex, iu);
 #pragma unroll
                     for (unsigned int o = 0; o < 4; o++)
-                        if (o < nex_i)
-                            ex_r[o] = __builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]);
+                        ex_r[o] = rl_u(hex[o], iu);
                     }
 
 #pragma unroll
