@@ -1158,18 +1158,24 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
 
     // ---- candidates into registers: fp32 coordinates relative to the block's first home particle, what a row stores
     // for them, and for every home cell q one word per lane with a bit per slab: is this candidate's cell adjacent to q ----
-    nl_v2f fx[MAXK / 2], fy[MAXK / 2], fz[MAXK / 2];
-    unsigned int co[MAXK];
-    unsigned int cidx[(EXCL && TILE) ? MAXK : 1];
+    // The rest of the kernel exists twice: for regions of up to six slabs of candidates (384: the rule where cells hold
+    // three particles) and for up to MAXK.  Every loop over the slabs is unrolled over the register arrays that hold
+    // them, so the short version runs half the loop bodies and their guards.
+    auto run = [&](auto kc)
+    {
+    constexpr int K = decltype(kc)::value;
+    nl_v2f fx[K / 2], fy[K / 2], fz[K / 2];
+    unsigned int co[K];
+    unsigned int cidx[(EXCL && TILE) ? K : 1];
     unsigned int adjw[hmd::TL_NH];
 #pragma unroll
     for (int q = 0; q < hmd::TL_NH; q++)
         adjw[q] = 0;
     // origin of the fp32 coordinates: the first candidate of the region (any fixed point near the block serves)
     double Ox = 0, Oy = 0, Oz = 0;
-    constexpr int BATCH = MAXK / 2;
+    constexpr int BATCH = K / 2;
 #pragma unroll
-    for (int b0 = 0; b0 < MAXK; b0 += BATCH)
+    for (int b0 = 0; b0 < K; b0 += BATCH)
         {
         unsigned int w_[BATCH], lo_[BATCH];
 #pragma unroll
@@ -1318,7 +1324,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
             if (band != 0u)
                 {
 #pragma unroll
-                for (int s = 0; s < MAXK / 2; s++)
+                for (int s = 0; s < K / 2; s++)
                     {
                     if ((unsigned int)(2 * s * 64) < T)
                         {
@@ -1371,7 +1377,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
                 auto leave_out = [&](unsigned int e)
                 {
 #pragma unroll
-                    for (int c = 0; c < MAXK; c++)
+                    for (int c = 0; c < K; c++)
                         if ((unsigned int)(c * 64) < T && (TILE ? cidx[c] : co[c]) == e)
                             bits &= ~(1u << (nslab - 1u - (unsigned int)c));
                 };
@@ -1398,7 +1404,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
                 unsigned int b = bits << (32u - nslab);
                 unsigned int pos = base - 1u;
 #pragma unroll
-                for (int c = 0; c < MAXK; c++)
+                for (int c = 0; c < K; c++)
                     {
                     if ((unsigned int)(c * 64) < T)
                         {
@@ -1433,7 +1439,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
                 // the row is longer than its capacity (the caller grows Nmax and builds again) or than the staging
                 // buffer: entries that have room go straight to memory
 #pragma unroll
-                for (int c = 0; c < MAXK; c++)
+                for (int c = 0; c < K; c++)
                     {
                     if ((unsigned int)(c * 64) < T)
                         {
@@ -1491,6 +1497,11 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
                 atomicMax(&a.d_conditions[0], cnt);
             }
         }
+    };
+    if (MAXK > 6 && T <= 6u * 64u)
+        run(std::integral_constant<int, (MAXK > 6 ? 6 : MAXK)> {});
+    else
+        run(std::integral_constant<int, MAXK> {});
     }
 
 template<bool ORTHO>
