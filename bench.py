@@ -211,8 +211,10 @@ def main():
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    cpp.poll_wait_seconds(True)
     t0 = time.perf_counter()
     sim.run(args.steps)
+    host_wait = cpp.poll_wait_seconds(False)  # (before the barrier: the time the run loop itself waited for published words)
     barrier()
     elapsed = time.perf_counter() - t0
     if prof is not None:
@@ -292,6 +294,9 @@ def main():
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
                              "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
                 "N": N_total, "equilibration_steps": args.equil, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
+                # share of the timed region the host spent waiting for words the device publishes (rebuild flags, build
+                # results): close to 1 when the device bounds the run, small when the host's own work does
+                "host_wait_fraction": host_wait / elapsed,
                 "shortest_rebuild": int(cell.shortest_rebuild), "tile_capacity": int(cell._cpp_obj.tile_capacity), "mean_listed_neighbors": listed / max(n_local, 1),
             },
             "roofline": {

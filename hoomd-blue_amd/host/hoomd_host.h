@@ -146,6 +146,8 @@ class PinnedWords
 //! wall-clock limit (HOOMD_AMD_POLL_TIMEOUT_S, default 120 s) the wait ends in a std::runtime_error that names `what`,
 //! the stamp and which of the streams still had work queued, so a stuck exchange ends the process instead of spinning.
 unsigned long long pollStampedWord(volatile unsigned long long* h, unsigned int stamp, const char* what, hipStream_t other = nullptr);
+//! seconds the host has spent inside pollStampedWord since the last reset
+double pollWaitSeconds(bool reset);
 
 //! Reads a few device words without a stream synchronisation: a one-wave kernel queued behind the producer
 //! stores them, stamped, to mapped pinned memory that the host polls (hmd_publish_words).

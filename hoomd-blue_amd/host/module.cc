@@ -139,6 +139,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
           return std::string(p.name) + " (" + p.gcnArchName + ")";
           });
     m.def("synchronize", []() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); });
+    m.def("poll_wait_seconds", &pollWaitSeconds, py::arg("reset") = false);
     m.def("abi_version", []() { return hmd_abi_version(); });
 
     m.def("enable_kernel_timing", [](bool on, const std::string& only, double min_us)

@@ -73,8 +73,26 @@ void WordReadback::finish(unsigned int* out, const char* what)
         out[k] = (unsigned int)pollStampedWord(h + k, m_stamp, what);
     }
 
+// time the host has spent waiting for published words (a run that is bound by the device spends most of its time here)
+static double g_poll_wait_s = 0.0;
+double pollWaitSeconds(bool reset)
+    {
+    const double v = g_poll_wait_s;
+    if (reset)
+        g_poll_wait_s = 0.0;
+    return v;
+    }
+
 unsigned long long pollStampedWord(volatile unsigned long long* h, unsigned int stamp, const char* what, hipStream_t other)
     {
+    struct Stopwatch
+        {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Stopwatch()
+            {
+            g_poll_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+        } stopwatch;
     static const double limit_s = []()
     {
         const char* e = std::getenv("HOOMD_AMD_POLL_TIMEOUT_S");
