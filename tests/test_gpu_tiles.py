@@ -245,12 +245,13 @@ def test_tile_forces_after_particles_wrap_between_builds(K, A):
         assert _rel_err(V_tile.cpu().numpy(), V_rows.cpu().numpy()) < F_RTOL * 1e-4
 
 
-@pytest.mark.parametrize("fast,wlo,whi", [(False, (1, 0, 1), (-2, -1, -1)), (True, (1, 0, 1), (-2, -1, -1)), (True, (0, 1, 0), (-1, -2, -2)),
-                                          (True, (1, 1, 1), (1, 1, 1))])
-def test_tile_forces_by_block_window(K, A, fast, wlo, whi):
+@pytest.mark.parametrize("fast,wlo,whi,rho", [(False, (1, 0, 1), (-2, -1, -1), 0.84), (True, (1, 0, 1), (-2, -1, -1), 0.84), (True, (0, 1, 0), (-1, -2, -2), 0.84),
+                                              (True, (1, 1, 1), (1, 1, 1), 0.84), (True, (1, 0, 1), (-2, -1, -1), 1.3)])
+def test_tile_forces_by_block_window(K, A, fast, wlo, whi, rho):
     """The blocks inside a window plus the blocks outside it give, bit for bit, what one launch over all
-    blocks gives; each launch writes only the particles of its own blocks."""
-    xyz, typ, L = liquid(20, seed=5)
+    blocks gives; each launch writes only the particles of its own blocks.  (Density 1.3: the kernel version with eight
+    waves per workgroup.)"""
+    xyz, typ, L = liquid(20 if rho < 1 else 24, rho=rho, jitter=0.12 if rho < 1 else 0.08, seed=5)
     N = len(xyz)
     gbox, obox = boxes(A, L)
     pos_t = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
