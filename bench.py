@@ -2,15 +2,23 @@
 """Headline benchmark: LJ liquid, N = 1,048,576 particles per GPU (rho = 0.84, kT = 1.5, r_cut = 2.5,
 buffer = 0.4, dt = 0.005, fp64), cell list -> neighbor list -> LJ pair force -> velocity Verlet.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --scaling strong                   (configuration C: 256x256x128 sites over 8 GPUs)
+    python bench.py --gpus 2 --backend gloo --lattice 48x48x48  (rehearsal: ranks sharing one GPU, host-staged)
 
 One "step" is one MD time step of the whole system.  Every run first equilibrates, untimed and whatever W
 is: the lattice is melted under a Berendsen thermostat and switched to NVE for the last 200 of --equil
 steps (config.equilibration_steps).  Then W untimed warm-up steps, then exactly K NVE steps are timed between
-barrier + device synchronisation on both sides; the maximum over ranks is used.  With N > 1 GPUs the
-box is replicated per GPU (weak scaling) and split by spatial domain decomposition with a halo
-exchange over RCCL.  Rank 0 prints one JSON line.
+barrier + device synchronisation on both sides; the maximum over ranks is used.  With N > 1 GPUs the system is split
+by spatial domain decomposition with a halo exchange over RCCL: --scaling weak (default) gives every GPU a sub-box of
+--lattice sites (128x128x64), --scaling strong splits ONE box of --lattice sites (256x256x128) over the GPUs.
+Rank 0 prints one JSON line.
+
+Started with --gpus N > 1 and no WORLD_SIZE in the environment, this file is its own launcher: the parent process
+touches no GPU, starts N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays
+rank 0's result line and exits non-zero as soon as any child has failed (the others are then stopped) or when
+--launch-timeout seconds have passed.
 
 `value` is particle-steps per second of the whole job; `timesteps_per_s` rides along.
 `roofline` prices the pair-force kernel: algorithmic bytes per launch = 4 * (listed neighbors) +
@@ -93,6 +101,85 @@ def cpu_baseline(snapshot, steps=150):
     }
 
 
+def launch_ranks(args, argv):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: starts one fresh child process per rank
+    and never touches a GPU itself (children are new processes, nothing is re-executed in a process that has
+    initialised the device).  Role of `mpirun -n 8` in the reference's own distributed tests
+    (hoomd/md/test/CMakeLists.txt:22-32,66-75)."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.backend == "nccl":
+        import torch  # (counting devices does not initialise the GPU)
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, one rank per GPU; this machine shows {have}.  "
+                  f"(Ranks sharing a GPU can only be rehearsed with --backend gloo.)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HOOMD_AMD_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), start_new_session=True))
+
+    def stop_all():
+        for p in procs:  # exactly the process groups started above
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().decode(errors="replace").splitlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                print(f"bench.py: rank {bad[0][0]} exited with status {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print(f"bench.py: ranks still running after --launch-timeout {args.launch_timeout} s; stopping them", file=sys.stderr)
+                rc = 3
+                break
+            time.sleep(0.1)
+    finally:
+        stop_all()
+    reader.join(timeout=5)
+    result = [ln for ln in lines if ln.startswith("{")]
+    if rc == 0 and not result:
+        print("bench.py: rank 0 ended without a result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(result[-1], flush=True)
+    return rc
+
+
 def main():
     # Libraries print banners on the C-level standard output (RCCL does at start-up): everything written to
     # file descriptor 1 goes to standard error until the result line, which is then the only line on stdout.
@@ -105,7 +192,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--equil", type=int, default=2000,
                     help="untimed equilibration steps before the warm-up: the lattice melts under the thermostat, the last 200 are NVE")
-    ap.add_argument("--lattice", type=str, default="128x128x64", help="lattice sites per GPU")
+    ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
+                    help="weak: --lattice sites PER GPU (default 128x128x64, N = 2^20 per GPU); strong: --lattice sites IN ALL "
+                         "(default 256x256x128, N = 2^23: configuration C) split over the GPUs by the least-surface grid")
+    ap.add_argument("--lattice", type=str, default=None, help="lattice sites per GPU (weak scaling) or of the whole system (strong scaling)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which a self-launched multi-rank run is stopped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tpp", type=int, default=0)
     ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka", "kg"],
@@ -120,6 +211,15 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="domain decomposition: do not compute interior blocks during the halo exchange")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks sharing one GPU)")
     args = ap.parse_args()
+    if args.lattice is None:
+        args.lattice = "128x128x64" if args.scaling == "weak" else "256x256x128"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only starts the ranks and relays the result
+        os.dup2(real_stdout, 1)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -128,9 +228,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.backend == "nccl" and world > max(torch.cuda.device_count(), 1):
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} GPUs, one rank per GPU; this machine shows {torch.cuda.device_count()} "
+                         "(ranks sharing a GPU can only be rehearsed with --backend gloo)")
 
     import hoomd_amd as hoomd
     from hoomd_amd import _hoomd_amd as cpp
@@ -138,12 +239,22 @@ def main():
 
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     decomposition = None
-    grid = grid_for(world)
+    lat = tuple(int(x) for x in args.lattice.split("x"))
+    if args.scaling == "weak":
+        grid = grid_for(world)
+        n, per_gpu = tuple(a * g for a, g in zip(lat, grid)), lat
+    else:
+        # one box for all GPUs, split by the least inter-domain surface (hoomd/DomainDecomposition.cc:327-408)
+        from hoomd_amd.comm import find_grid
+        grid = find_grid(world, [float(a) for a in lat])
+        n, per_gpu = lat, tuple(a // g for a, g in zip(lat, grid))
     if world > 1 or args.force_dd:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL's stream on a high-priority hardware queue: its kernels then run beside the force kernel of the
-        # default stream instead of lining up behind it
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        # HOOMD_AMD_COMM_PRIORITY=high: exchange stream (and RCCL's own stream when torch issues the collectives) on a
+        # high-priority hardware queue, so their kernels run beside the force kernel of the default stream instead of
+        # lining up behind it.  Normal priority is the default: no run with peers at high priority is on record.
+        if os.environ.get("HOOMD_AMD_COMM_PRIORITY") == "high":
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -155,8 +266,6 @@ def main():
         from hoomd_amd import comm
         decomposition = comm.DomainDecomposition(grid=grid)
 
-    per_gpu = tuple(int(x) for x in args.lattice.split("x"))
-    n = tuple(a * g for a, g in zip(per_gpu, grid))
     if args.workload == "ka":
         thermostat = hoomd.md.methods.thermostats.Bussi(kT=1.0)
         sim, cell, lj, method = lj_liquid.make_ka_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
@@ -192,9 +301,15 @@ def main():
     sim.run(melt)
     if args.workload != "ka":
         method.thermostat = None  # the Kob-Andersen case keeps its thermostat, as the reference configuration does
+    cell._cpp_obj.resetStats()
     sim.run(args.equil - melt)
     # ---- warm-up: W more steps of exactly what is timed ----
     sim.run(args.warmup)
+    # mean rebuild period of the liquid as it is timed, from the steps just run (the timed window may hold one rebuild
+    # more or fewer than steps / period: with 20 steps and a period of 6 that is 3 or 4, a difference of 10 % of the line)
+    steps_before = args.equil - melt + args.warmup
+    builds_before = int(cell.num_builds)
+    mean_period = steps_before / builds_before if builds_before else None
 
     # ---- timed region ----
     cell._cpp_obj.resetStats()
@@ -253,21 +368,31 @@ def main():
         ms += timing["pair_force_interior"][1]
         calls = args.steps
     avg_s = (ms / 1e3 / calls) if calls else float("nan")
-    algo_bytes = 4.0 * listed + 76.0 * n_local + (228.0 * n_local if rider else 0.0)
+    # the integration pass adds 196 bytes per particle (228 for the joined half steps + check + slot copy, less the 32 of
+    # the force the same wave has just stored: reading it back is not compulsory traffic)
+    INTEGRATION_BYTES = 196.0
+    algo_bytes = 4.0 * listed + 76.0 * n_local + (INTEGRATION_BYTES * n_local if rider else 0.0)
     achieved = algo_bytes / avg_s / 1e9 if calls else float("nan")
     fp64_tflops = FLOP_PER_LISTED_PAIR * listed / avg_s / 1e12 if calls else float("nan")
 
     # HBM traffic of the pair-force kernel per launch from the L2 memory-side counters (FETCH_SIZE / WRITE_SIZE in
     # separate rocprofv3 --pmc passes, scripts/measure_traffic.sh): counters cannot be read from inside this
-    # process, so the figure measured for this configuration is carried in profiles/
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02c_traffic.json")) as f:
-            tr = json.load(f)
-        if tr.get("N") == n_local and world == 1:
-            traffic = tr["kernels"]["pair_force_tiles_kernel_step" if rider else "pair_force_tiles_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # process, so the figure is CARRIED from the newest file in profiles/ measured on the same workload, N and kind of
+    # launch; `traffic_source` names that file (null when none matches: other workload, other size, decomposed run)
+    traffic, traffic_source = None, None
+    kernel_key = "pair_force_tiles_kernel_step" if rider else "pair_force_tiles_kernel" if cell._cpp_obj.tiles_active else "pair_force_kernel"
+    if world == 1 and decomposition is None:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    tr = json.load(f)
+                if tr.get("N") == n_local and tr.get("workload", "lj") == args.workload and kernel_key in tr["kernels"]:
+                    traffic = tr["kernels"][kernel_key]["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/" + os.path.basename(path) + " (separate rocprofv3 --pmc run; carried, not measured by this process)"
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
 
     if rank == 0:
         out = {
@@ -280,7 +405,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -294,6 +419,8 @@ def main():
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "
                              "r_cut=2.5 buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume (NVE), fp64"),
                 "N": N_total, "equilibration_steps": args.equil, "domain_grid": list(grid), "rebuilds_in_timed_region": int(cell.num_builds),
+                "mean_rebuild_period_before_timed_region": mean_period,
+                "expected_rebuilds_in_window": (args.steps / mean_period) if mean_period else None,
                 # share of the timed region the host spent waiting for words the device publishes (rebuild flags, build
                 # results): close to 1 when the device bounds the run, small when the host's own work does
                 "host_wait_fraction": host_wait / elapsed,
@@ -303,10 +430,13 @@ def main():
                 "kernel": ("pair_force_tiles_kernel<EvaluatorPairLJ, STEP> (rank 0): pair force + second half step + next first half step + distance check"
                            if rider else "pair_force_tiles_kernel<EvaluatorPairLJ> (rank 0)" if cell._cpp_obj.tiles_active
                            else "pair_force_kernel<EvaluatorPairLJ> (rank 0)"),
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
+                # the nearer ceiling of the two this kernel is priced against: "hbm" when its share of the HBM peak is the
+                # larger one, "fp64-valu" when its share of the fp64 vector peak is (achieved / peak stay the HBM figures)
+                "bound": "hbm" if achieved / HBM_PEAK_GBS >= fp64_tflops / FP64_VECTOR_PEAK_TFLOPS else "fp64-valu",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": 1e6 * avg_s, "launches": int(calls), "algorithmic_bytes_per_launch": algo_bytes,
                 "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS, "fp64_frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
-                "pair_force_bytes_per_launch": 4.0 * listed + 76.0 * n_local, "integration_bytes_per_launch": 228.0 * n_local if rider else 0.0,
+                "pair_force_bytes_per_launch": 4.0 * listed + 76.0 * n_local, "integration_bytes_per_launch": INTEGRATION_BYTES * n_local if rider else 0.0,
                 "launches_without_the_integration_pass": plain,
             },
         }

@@ -56,10 +56,44 @@ struct nl_excl_t
     hmd_index2d_t exli;
     };
 
+// Half-width of the band of squared distances in which "p_i - (p_j + image)" and the CPU path's
+// "(p_i - p_j) - image" may fall on different sides of r_list^2.  Both are roundings of the same real number: the
+// shifted candidate carries an error of half an ulp of 1.5 |box|, the CPU path's difference one of half an ulp of
+// |box|, so the components differ by less than 2^-51 |box| and the squared distances of a pair near r_list by less than
+// 2 sqrt(3) r_list 2^-51 |box| < 2^-48 (r_list^2 + |box|^2) / 2.  |box| is the sum of the lengths of the box vectors'
+// components.  (About one candidate in 10^9 falls into the band.)
+__device__ __forceinline__ double nl_exact_band_box(const hmd_box_t& b)
+    {
+    const double l = b.L[0] + b.L[1] * (1.0 + fabs(b.xy)) + b.L[2] * (1.0 + fabs(b.xz) + fabs(b.yz));
+    return 3.5527136788005009e-15 * l * l; // 2^-48
+    }
+
+// The CPU path's squared distance of home particle (pix, piy, piz) and a candidate at (cx, cy, cz) (coordinates as
+// stored, not shifted) seen through the periodic image (ix, iy, iz) of its cell: the difference first, then
+// BoxDim::minImage's subtractions in its order -- z image (with its tilt terms on y and x), y image (tilt on x), x
+// image -- every product and difference rounded on its own (hoomd/md/NeighborListBinned.cc:150-157,
+// hoomd/BoxDim.h:327-372).
+__device__ __forceinline__ double nl_exact_rsq(const hmd_box_t& b, double pix, double piy, double piz, double cx, double cy, double cz, unsigned int code)
+    {
+    const double ix = (double)((int)(code & 3u) - 1), iy = (double)((int)((code >> 2) & 3u) - 1), iz = (double)((int)((code >> 4) & 3u) - 1);
+    double dx = HMD_SUB(pix, cx), dy = HMD_SUB(piy, cy), dz = HMD_SUB(piz, cz);
+    dz = HMD_SUB(dz, HMD_MUL(b.L[2], iz));
+    dy = HMD_SUB(dy, HMD_MUL(HMD_MUL(b.L[2], b.yz), iz));
+    dx = HMD_SUB(dx, HMD_MUL(HMD_MUL(b.L[2], b.xz), iz));
+    dy = HMD_SUB(dy, HMD_MUL(b.L[1], iy));
+    dx = HMD_SUB(dx, HMD_MUL(HMD_MUL(b.L[1], b.xy), iy));
+    dx = HMD_SUB(dx, HMD_MUL(b.L[0], ix));
+    return HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz));
+    }
+
 // MODE 0: minimum image per pair (any box); 1: the same for orthorhombic boxes; 2: the periodic image
 // of every adjacent cell is fixed up front (possible when each periodic direction has at least three
 // cells: the 3x3x3 stencil then never holds two images of one cell), so candidates are shifted once
 // when they are loaded and no minimum-image arithmetic (hoomd/BoxDim.h:306-325) runs per pair.
+// p_i - (p_j + image) is not the CPU path's (p_i - p_j) - image in the last bit, so in MODE 2 a squared distance
+// within a band around r_list^2 that is wider than the two can differ (nl_exact_band) is computed again from the
+// candidate's stored coordinates with the CPU path's own sequence of operations (nl_exact_rsq): the neighbor SET is
+// the CPU path's also for pairs within an ulp of r_list across a periodic face.
 // TILE (needs MODE 2): rows receive 16-bit tile slots (tile_slot() of the candidate number in the 4x4x4-cell
 // region around the home cell's 2x2x2 block, tile.cuh) instead of particle indices, padded to a multiple
 // of four with the slot after the region's last candidate, where consumers keep a dummy far away.
@@ -75,7 +109,8 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     unsigned int* s_cell_all = s_excl_all + 64 * NL_WAVES;
     double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
     unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * NL_WAVES);
-    double* s_rl2 = reinterpret_cast<double*>(s_tileoff_all + 64 * NL_WAVES);
+    unsigned int* s_img_all = s_tileoff_all + 64 * NL_WAVES;
+    double* s_rl2 = reinterpret_cast<double*>(s_img_all + 64 * NL_WAVES);
 
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,6 +118,8 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     unsigned int* s_cell = s_cell_all + 64 * wave;
     double* s_shift = s_shift_all + 3 * 64 * wave;
     unsigned int* s_tileoff = s_tileoff_all + 64 * wave;
+    unsigned int* s_img = s_img_all + 64 * wave; // (ix + 1) | (iy + 1) << 2 | (iz + 1) << 4 of every adjacent cell
+    const double band_box = MODE == 2 ? nl_exact_band_box(a.box) : 0.0;
 
     if (!SINGLE_TYPE)
         {
@@ -138,17 +175,20 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         // image of the adjacent cell seen from the home cell: its grid coordinate differs by -1, 0 or +1
         // after unwrapping; r_image = r + ix*a1 + iy*a2 + iz*a3 (box vectors as in hoomd/BoxDim.h:391-458)
         double sx = 0.0, sy = 0.0, sz = 0.0;
+        unsigned int code = 1u | (1u << 2) | (1u << 4);
         if (lane < n_adj)
             {
             const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
             const int hc[3] = {(int)(cell % a.ci.w), (int)((cell / a.ci.w) % a.ci.h), (int)(cell / (a.ci.w * a.ci.h))};
             const int ac[3] = {(int)(adj_cell % a.ci.w), (int)((adj_cell / a.ci.w) % a.ci.h), (int)(adj_cell / (a.ci.w * a.ci.h))};
             double img[3];
+            code = 0u;
 #pragma unroll
             for (int d = 0; d < 3; d++)
                 {
                 const int diff = ac[d] - hc[d];
                 img[d] = (a.box.periodic[d] && dim[d] >= 3) ? (diff > 1 ? -1.0 : (diff < -1 ? 1.0 : 0.0)) : 0.0;
+                code |= (unsigned int)((int)img[d] + 1) << (2 * d);
                 }
             sx = img[0] * a.box.L[0] + img[1] * (a.box.L[1] * a.box.xy) + img[2] * (a.box.L[2] * a.box.xz);
             sy = img[1] * a.box.L[1] + img[2] * (a.box.L[2] * a.box.yz);
@@ -157,6 +197,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         s_shift[3 * lane + 0] = sx;
         s_shift[3 * lane + 1] = sy;
         s_shift[3 * lane + 2] = sz;
+        s_img[lane] = code;
         }
     unsigned int tile_pad = 0; // what pads a tile row: the slot of the consumers' dummy candidate
     // tile rows: number of the home cell's first member among the home particles of its block, the block's
@@ -357,8 +398,24 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         double dz = HMD_SUB(piz, cz[c]);
                         if (MODE != 2)
                             hmd_min_image<MODE == 1>(a.box, dx, dy, dz);
-                        const double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz));
+                        double rsq = HMD_ADD(HMD_ADD(HMD_MUL(dx, dx), HMD_MUL(dy, dy)), HMD_MUL(dz, dz));
                         const double rl2 = SINGLE_TYPE ? rl2_single : s_rl2[hmd_idx2(hmd_index2d_t {a.ntypes, a.ntypes}, ti, ct[c])];
+                        if (MODE == 2 && fabs(rsq - rl2) <= band_box + 3.5527136788005009e-15 * rl2)
+                            {
+                            // (rare) too close to r_list^2 for the shifted candidate: the CPU path's arithmetic on the
+                            // coordinates as stored
+                            const unsigned int k = pbase + c * 64 + lane;
+                            unsigned int lo = 0;
+#pragma unroll
+                            for (unsigned int step = 32; step > 0; step >>= 1)
+                                {
+                                const unsigned int t = lo + step;
+                                if (t < n_adj && s_excl[t] <= k)
+                                    lo = t;
+                                }
+                            const double4 v = hmd_ld4(a.d_cell_xyzf + hmd_idx2(a.cli, k - s_excl[lo], s_cell[lo]));
+                            rsq = nl_exact_rsq(a.box, pix, piy, piz, v.x, v.y, v.z, s_img[lo]);
+                            }
                         bool hit = (rsq <= rl2) && (cj[c] != i_idx);
                         if (FILTER_BODY)
                             hit = hit && !(body_i != HMD_NO_BODY && body_i == cb[c]);
@@ -1898,7 +1955,7 @@ int nlist_binned_driver(const hmd_nlist_binned_args_t& a, hipStream_t s, unsigne
         wpc = 2;
     if (ncells < 2048)
         wpc = 4;
-    const size_t lds = (sizeof(unsigned int) * 192 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
+    const size_t lds = (sizeof(unsigned int) * 256 + sizeof(double) * 3 * 64) * NL_WAVES + (single ? 0 : sizeof(double) * a.ntypes * a.ntypes);
     if (single && !fb)
         return launch_nlist<true, false>(a, ncells, wpc, lds, s, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
     if (single && fb)
@@ -2102,6 +2159,17 @@ extern "C" int hmd_nlist_build_head_list_noalloc(const hmd_head_list_args_t* arg
     if (e != hipSuccess)
         return (int)e;
     HMD_REQUIRE(dev >= 0 && dev < HL_NOALLOC_MAX_DEVICES, HMD_ERR_TOO_LARGE, "hmd_nlist_build_head_list_noalloc: device ordinal above 63");
+    if (stream)
+        {
+        // every GPU has its own copy of the array: the one used must be the copy of the GPU the stream runs on
+        int sdev = -1;
+        e = hipStreamGetDevice((hipStream_t)stream, &sdev);
+        if (e != hipSuccess)
+            return (int)e;
+        HMD_REQUIRE(sdev == dev, HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_nlist_build_head_list_noalloc: the stream belongs to another GPU than the current one (make the stream's device "
+                    "current before the call)");
+        }
     unsigned long long* tiles = nullptr;
         {
         std::lock_guard<std::mutex> lock(g_hl_scratch_mutex);

@@ -241,8 +241,9 @@ class DomainDecomposition:
 
     def _nlist_attached(self, nlist):
         self.communicator.add_nlist(nlist)
-        if self.ranks_share_a_gpu():
-            nlist._cpp_obj.comm_stream_high_priority = False
+        nlist._cpp_obj.ranks_share_gpu = bool(self.ranks_share_a_gpu())
+        if os.environ.get("HOOMD_AMD_COMM_PRIORITY") == "high" and not self.ranks_share_a_gpu():
+            nlist._cpp_obj.comm_stream_high_priority = True
 
     def _allreduce_sum_list(self, values):
         tr = self.communicator.transport if self.communicator is not None else None
@@ -541,6 +542,11 @@ class TorchTransport(getattr(_cpp, "ExchangeTransport", object)):
                 cur.synchronize()
             else:
                 dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+
+    def allReduceSumHost(self, values):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device="cpu" if self.stage else self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.tolist()
 
     def anyRank(self, local):
         self._vote.fill_(1 if local else 0)

@@ -6,8 +6,82 @@ from ..error import DataAccessError
 from ..operation import AutotunedObject
 
 
+class DeviceArrayView:
+    """Read-only view of one of the neighbor list's device buffers (role of hoomd.data.array.HOOMDGPUArray,
+    hoomd/data/array.py): carries ``__cuda_array_interface__`` (version 2: shape, typestr, data pointer, read-only), so
+    ``torch.as_tensor(view, device="cuda")`` or ``cupy.asarray(view)`` wrap the same memory without a copy.  Valid only
+    inside the ``with`` block that handed it out."""
+
+    def __init__(self, owner, ptr, shape, typestr):
+        self._owner = owner
+        self._ptr, self._shape, self._typestr = int(ptr), tuple(int(v) for v in shape), typestr
+
+    @property
+    def __cuda_array_interface__(self):
+        self._owner._check()
+        return {"shape": self._shape, "typestr": self._typestr, "data": (self._ptr, True), "version": 2}
+
+    shape = property(lambda self: self._shape)
+    dtype = property(lambda self: np.dtype(self._typestr))
+    read_only = True
+
+    def __len__(self):
+        return self._shape[0]
+
+
+class NeighborListLocalAccessGPU:
+    """``with nlist.gpu_local_nlist_arrays as data:`` -- the list's buffers on the GPU (hoomd/md/data/local_access_gpu.py,
+    C++ side LocalNeighborListDataDevice, hoomd/md/NeighborList.h:662-739).  The neighbors of local particle i are
+    ``nlist[head_list[i] : head_list[i] + n_neigh[i]]`` (local indices; ghosts have indices >= N).  Rank-local and
+    read-only; the views die with the block (the next rebuild may move or rewrite the buffers)."""
+
+    def __init__(self, nlist):
+        self._nlist = nlist
+        self._entered = False
+        self._views = None
+
+    def _check(self):
+        if not self._entered:
+            raise RuntimeError("neighbor-list device arrays are only valid inside the `with` block of gpu_local_nlist_arrays")
+
+    def __enter__(self):
+        nl = self._nlist
+        if nl._in_context_manager:
+            raise RuntimeError("Cannot enter gpu_local_nlist_arrays context manager inside another local_nlist_arrays context manager")
+        cpp = nl._cpp_obj
+        n = nl._sim._sysdef.getParticleData().N
+        size = int(cpp.nlist_size)           # expands index rows from the tile rows when the last build wrote those
+        _cpp.synchronize()                   # consumers on other streams see finished buffers
+        self._views = dict(head_list=DeviceArrayView(self, cpp.head_list_ptr, (n,), "<u8"),
+                           n_neigh=DeviceArrayView(self, cpp.n_neigh_ptr, (n,), "<u4"),
+                           nlist=DeviceArrayView(self, cpp.nlist_ptr, (size,), "<u4"))
+        nl._in_context_manager = True
+        self._entered = True
+        return self
+
+    def __exit__(self, *exc):
+        self._entered = False
+        self._nlist._in_context_manager = False
+        self._views = None
+        return False
+
+    def _get(self, name):
+        self._check()
+        return self._views[name]
+
+    head_list = property(lambda self: self._get("head_list"))
+    n_neigh = property(lambda self: self._get("n_neigh"))
+    nlist = property(lambda self: self._get("nlist"))
+
+    @property
+    def half_nlist(self):
+        self._check()
+        return False  # the GPU path stores the full list (hoomd/md/NeighborListGPUBinned.cc:51-54)
+
+
 class NeighborList(AutotunedObject):
     """Base class (hoomd/md/nlist.py:84-323)."""
+    _in_context_manager = False
 
     def __init__(self, buffer, exclusions, rebuild_check_delay, check_dist, mesh):
         if mesh is not None:
@@ -108,6 +182,16 @@ class NeighborList(AutotunedObject):
         n = self._sim._sysdef.getParticleData().N
         return dict(head_list=np.asarray(self._cpp_obj.getHeadListArray(n)), n_neigh=np.asarray(self._cpp_obj.getNNeighArray(n)),
                     nlist=np.asarray(self._cpp_obj.getNListArray()), half_nlist=False)
+
+    @property
+    def gpu_local_nlist_arrays(self):
+        """Zero-copy, read-only device views of (head_list, n_neigh, nlist) for use in a ``with`` block
+        (hoomd/md/nlist.py:187-233)."""
+        self._require_attached("gpu_local_nlist_arrays")
+        if self._in_context_manager:
+            raise RuntimeError("Cannot enter gpu_local_nlist_arrays context manager inside another local_nlist_arrays context manager")
+        self._cpp_obj.compute(self._sim.timestep)
+        return NeighborListLocalAccessGPU(self)
 
 
 class Cell(NeighborList):

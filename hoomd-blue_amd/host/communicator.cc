@@ -270,11 +270,11 @@ bool CommunicatorGPU::migrateParticles()
             {
             slot_rows = m_mig_slot_rows;
             const size_t rows = (size_t)m_world * (slot_rows + 1);
+            // (each on its own: the exchange with counts grows them independently, and the two forms can alternate)
             if (m_mig_out.size() < rows * ROW_WORDS)
-                {
                 m_mig_out.resize(rows * ROW_WORDS, false);
+            if (m_mig_in.size() < rows * ROW_WORDS)
                 m_mig_in.resize(rows * ROW_WORDS, false);
-                }
             pk.slot_rows = slot_rows;
             pk.d_out = m_mig_out.get();
             abiCheck(hmd_migrate_pack(&pk, nullptr), "hmd_migrate_pack");
@@ -619,6 +619,7 @@ uintptr_t CommunicatorGPU::beginRebuildVote(uintptr_t d_flag, unsigned int check
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     m_vote_word = word;
     m_vote_checkn = checkn;
+    m_vote_stream = s;
     if (m_in_communicate && !m_force_migrate && !m_ghosts_fresh)
         {
         m_ghosts_fresh = true;
@@ -636,7 +637,9 @@ uintptr_t CommunicatorGPU::beginRebuildVote(uintptr_t d_flag, unsigned int check
 bool CommunicatorGPU::endRebuildVote()
     {
     unsigned int v = 0;
-    hipCheck(hipMemcpy(&v, m_vote_word, sizeof(v), hipMemcpyDeviceToHost), "vote D2H");
+    // the vote was queued on m_vote_stream, which may be a non-blocking stream the null stream does not order after
+    hipCheck(hipMemcpyAsync(&v, m_vote_word, sizeof(v), hipMemcpyDeviceToHost, m_vote_stream), "vote D2H");
+    hipCheck(hipStreamSynchronize(m_vote_stream), "vote D2H");
     return v == m_vote_checkn;
     }
 

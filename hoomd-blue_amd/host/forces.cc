@@ -82,6 +82,8 @@ Scalar ForceCompute::calcEnergySum()
     double pe = m_external_energy;
     for (unsigned int i = 0; i < n; i++)
         pe += f[i].w;
+    if (m_sysdef->isDomainDecomposed())
+        m_sysdef->getCommunicator()->allReduceSum(&pe, 1);
     return pe;
     }
 

@@ -277,6 +277,12 @@ class ParticleData
         {
         return m_nglobal;
         }
+    //! counts the times the particle set was replaced as a whole (initializeFromSnapshot): anything derived from the
+    //! composition of the system -- global per-type particle counts -- is stale when it has changed
+    uint64_t getCompositionGeneration() const
+        {
+        return m_composition_generation;
+        }
     void setNGlobal(unsigned int n)
         {
         m_nglobal = n;
@@ -532,6 +538,7 @@ class ParticleData
     Scalar m_external_energy = 0;
     Scalar m_external_virial[6] = {0, 0, 0, 0, 0, 0};
     Signal m_sort_signal, m_box_signal, m_maxn_signal, m_nglobal_signal;
+    uint64_t m_composition_generation = 0;
     uint64_t m_sort_count = 0;
     };
 
@@ -672,6 +679,12 @@ class Communicator
     virtual bool endRebuildVote()
         {
         return false;
+        }
+    //! in-place sum over all ranks of n host doubles (hoomd/ForceCompute.cc:218, hoomd/md/PotentialPair.h:430)
+    virtual void allReduceSum(double* v, int n) { }
+    virtual unsigned int getRank() const
+        {
+        return 0;
         }
     };
 
@@ -1107,18 +1120,31 @@ class NeighborListGPUBinned : public Compute
         {
         return m_n_overlapped;
         }
-    //! Priority of the stream the halo exchange runs on beside the interior force launch.  High (the default) keeps
-    //! the exchange's small kernels on a hardware queue of their own.  It must be normal when several processes
-    //! share this GPU: their queues then outnumber the hardware's, the scheduler maps queues by priority, and a
-    //! high-priority queue that waits for an event of its own process's normal-priority queue keeps that queue
-    //! (and everyone else's) from ever running.  Takes effect when the stream is created (first overlapped step).
+    //! Priority of the stream the halo exchange runs on beside the interior force launch.  Normal by default.  High
+    //! (HOOMD_AMD_COMM_PRIORITY=high, or this setter) keeps the exchange's small kernels on a hardware queue of their
+    //! own, ahead of the force kernel's workgroups; it has only ever run with one rank per GPU and no peers, and it
+    //! must never be used when several processes share a GPU: their queues then outnumber the hardware's, the
+    //! scheduler maps queues by priority, and a high-priority queue that waits for an event of its own process's
+    //! normal-priority queue keeps that queue (and everyone else's) from ever running.  Takes effect when the stream
+    //! is created (first overlapped step).
     void setCommStreamHighPriority(bool high)
         {
         m_comm_high_priority = high;
         }
     bool getCommStreamHighPriority() const
         {
-        return m_comm_high_priority;
+        return m_comm_high_priority && !m_ranks_share_gpu;
+        }
+    //! told by the decomposition when two ranks of the run use one GPU: the exchange stream then stays at normal priority
+    void setRanksShareGPU(bool b)
+        {
+        m_ranks_share_gpu = b;
+        if (b)
+            m_comm_high_priority = false;
+        }
+    bool getRanksShareGPU() const
+        {
+        return m_ranks_share_gpu;
         }
 
     //! time step of the last (re)build
@@ -1196,7 +1222,7 @@ class NeighborListGPUBinned : public Compute
     hipStream_t m_comm_stream = nullptr;
     hipEvent_t m_ev_ready = nullptr, m_ev_comm = nullptr;
     bool m_overlap = true;
-    bool m_comm_high_priority = true;
+    bool m_comm_high_priority = false, m_ranks_share_gpu = false;
     uint64_t m_n_overlapped = 0;
     WordReadback m_readback;
     bool m_in_compute = false;
@@ -1815,6 +1841,11 @@ class ExchangeTransport
     virtual void allReduceMaxWord(uintptr_t d_word, uintptr_t stream) = 0;
     //! logical OR of a host flag over all ranks
     virtual bool anyRank(bool local) = 0;
+    //! sum over all ranks of a few host doubles (energies, particle counts per type); every rank calls
+    virtual std::vector<double> allReduceSumHost(const std::vector<double>& v)
+        {
+        throw std::runtime_error("this exchange transport has no host-side sum");
+        }
     };
 
 class CommunicatorGPU : public Communicator
@@ -1839,6 +1870,17 @@ class CommunicatorGPU : public Communicator
         }
     uintptr_t beginRebuildVote(uintptr_t d_flag, unsigned int checkn, uintptr_t stream) override;
     bool endRebuildVote() override;
+    void allReduceSum(double* v, int n) override
+        {
+        const std::vector<double> r = m_transport->allReduceSumHost(std::vector<double>(v, v + n));
+        if ((int)r.size() != n)
+            throw std::runtime_error("allReduceSumHost returned another number of values");
+        std::copy(r.begin(), r.end(), v);
+        }
+    unsigned int getRank() const override
+        {
+        return m_rank;
+        }
 
     //! hoomd/Communicator.cc migrateParticles; true when this rank's particle set changed
     bool migrateParticles();
@@ -1931,6 +1973,7 @@ class CommunicatorGPU : public Communicator
     // the vote in flight
     unsigned int* m_vote_word = nullptr;
     unsigned int m_vote_checkn = 0;
+    hipStream_t m_vote_stream = nullptr;
     };
 
 // A plugin built outside the tree holds the layout of the classes above in its own objects (their inline accessors,

@@ -117,6 +117,10 @@ class PyExchangeTransport : public ExchangeTransport
         {
         PYBIND11_OVERRIDE_PURE(bool, ExchangeTransport, anyRank, local);
         }
+    std::vector<double> allReduceSumHost(const std::vector<double>& v) override
+        {
+        PYBIND11_OVERRIDE(std::vector<double>, ExchangeTransport, allReduceSumHost, v);
+        }
     };
     } // namespace
 
@@ -332,6 +336,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)
         .def_property_readonly("num_overlapped", &NeighborListGPUBinned::getNumOverlapped)
         .def_property("comm_stream_high_priority", &NeighborListGPUBinned::getCommStreamHighPriority, &NeighborListGPUBinned::setCommStreamHighPriority)
+        .def_property("ranks_share_gpu", &NeighborListGPUBinned::getRanksShareGPU, &NeighborListGPUBinned::setRanksShareGPU)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)
         .def("setFilterBody", &NeighborListGPUBinned::setFilterBody)
@@ -389,6 +394,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("getNListArray", [](NeighborListGPUBinned& n) { return to_np1(n.getNListArray().toHost()); })
         .def_property_readonly("n_neigh_ptr", [](NeighborListGPUBinned& n) { return (uintptr_t)n.getNNeighArray().get(); })
         .def_property_readonly("nlist_ptr", [](NeighborListGPUBinned& n) { return (uintptr_t)n.getNListArray().get(); })
+        .def_property_readonly("nlist_size", [](NeighborListGPUBinned& n) { return n.getNListArray().size(); })
         .def_property_readonly("head_list_ptr", [](NeighborListGPUBinned& n) { return (uintptr_t)n.getHeadList().get(); });
 
     py::class_<ForceCompute, std::shared_ptr<ForceCompute>>(m, "ForceCompute")

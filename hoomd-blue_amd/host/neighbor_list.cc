@@ -272,17 +272,18 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
             {
             if (!m_comm_stream)
                 {
-                // highest priority (unless the communicator found several ranks on this GPU, see
-                // setCommStreamHighPriority): the runtime keeps such streams on hardware queues of their own, so the
-                // exchange's small kernels are not lined up behind the force kernel of the default stream.
-                // HOOMD_AMD_COMM_PRIORITY=normal|high overrides the choice (experiments).
+                // normal priority unless asked otherwise (setCommStreamHighPriority, HOOMD_AMD_COMM_PRIORITY=high):
+                // the runtime keeps high-priority streams on hardware queues of their own, so the exchange's small
+                // kernels are not lined up behind the force kernel of the default stream -- but a high-priority
+                // queue waiting on an event has starved normal-priority queues when ranks shared a GPU, and no run
+                // with peers at high priority is on record.  Ranks that share a GPU always get normal priority.
                 int least = 0, greatest = 0;
                 hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
                 const char* prio = std::getenv("HOOMD_AMD_COMM_PRIORITY");
-                bool high = m_comm_high_priority;
+                bool high = m_comm_high_priority && !m_ranks_share_gpu;
                 if (prio && std::string(prio) == "normal")
                     high = false;
-                else if (prio && std::string(prio) == "high")
+                else if (prio && std::string(prio) == "high" && !m_ranks_share_gpu)
                     high = true;
                 hipCheck(hipStreamCreateWithPriority(&m_comm_stream, hipStreamNonBlocking, high ? greatest : 0), "hipStreamCreateWithPriority");
                 hipCheck(hipEventCreateWithFlags(&m_ev_ready, hipEventDisableTiming), "hipEventCreateWithFlags");

@@ -299,6 +299,7 @@ void ParticleData::initializeFromSnapshot(const SnapshotParticleData& snap)
     m_accel_set = false;
     for (unsigned int i = 0; i < n && !m_accel_set; i++)
         m_accel_set = snap.accel[i][0] != 0 || snap.accel[i][1] != 0 || snap.accel[i][2] != 0;
+    m_composition_generation++;
     notifyParticleSort();
     }
 

@@ -142,8 +142,12 @@ template<class evaluator> class PotentialPair : public ForceCompute
         if (typ1 >= m_ntypes || typ2 >= m_ntypes)
             throw std::invalid_argument("Error " + action + " in PotentialPair: pair." + std::string(evaluator::getName()) + ": invalid type");
         }
-    //! hoomd/md/PotentialPair.h:255-341 (the per-type counts come from the type ids of the local particles)
+    //! hoomd/md/PotentialPair.h:255-341: corrections from the GLOBAL number of particles of every type
+    //! (:283-337, counted once and again only when the particle set is replaced; summed over ranks under domain
+    //! decomposition as in :430), added on rank 0 only so that the sum over ranks holds them once
     void computeTailCorrection();
+    std::vector<double> m_type_count;
+    uint64_t m_type_count_generation = ~0ull;
 
     std::shared_ptr<NeighborList> m_nlist;
     unsigned int m_ntypes;
@@ -230,16 +234,31 @@ template<class evaluator> void PotentialPair<evaluator>::computeTailCorrection()
         return;
     if (m_shift_mode != no_shift)
         throw std::runtime_error("Pair potential shift mode must be \"none\" to apply tail corrections.");
-    const unsigned int n = m_pdata->getN();
-    std::vector<Scalar4> pos(n);
-    if (n)
-        hipCheck(hipMemcpy(pos.data(), m_pdata->pos(), sizeof(Scalar4) * n, hipMemcpyDeviceToHost), "pos D2H");
-    std::vector<unsigned int> count(m_ntypes, 0);
-    for (auto& p : pos)
+    const bool decomposed = m_sysdef->isDomainDecomposed();
+    if (m_type_count_generation != m_pdata->getCompositionGeneration() || m_type_count.size() != m_ntypes)
         {
-        unsigned int t;
-        std::memcpy(&t, &p.w, sizeof(unsigned int));
-        count[t]++;
+        const unsigned int n = m_pdata->getN();
+        std::vector<Scalar4> pos(n);
+        if (n)
+            hipCheck(hipMemcpy(pos.data(), m_pdata->pos(), sizeof(Scalar4) * n, hipMemcpyDeviceToHost), "pos D2H");
+        m_type_count.assign(m_ntypes, 0.0);
+        for (auto& p : pos)
+            {
+            unsigned int t;
+            std::memcpy(&t, &p.w, sizeof(unsigned int));
+            m_type_count[t] += 1.0;
+            }
+        if (decomposed)
+            m_sysdef->getCommunicator()->allReduceSum(m_type_count.data(), (int)m_ntypes);
+        m_type_count_generation = m_pdata->getCompositionGeneration();
+        }
+    const std::vector<double>& count = m_type_count;
+    if (decomposed && m_sysdef->getCommunicator()->getRank() != 0)
+        {
+        m_external_energy = 0;
+        for (auto& v : m_external_virial)
+            v = 0;
+        return;
         }
     const bool twod = m_sysdef->getNDimensions() == 2;
     const Scalar volume = m_pdata->getGlobalBox().getVolume(twod);

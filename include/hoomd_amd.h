@@ -207,7 +207,10 @@ int hmd_nlist_build_head_list(const hmd_head_list_args_t* args, void* stream);
    the scan live in a static device array inside the library (64 KiB per GPU, held until the process
    ends), sized for N <= 16,777,216; a larger N returns HMD_ERR_TOO_LARGE.  Same outputs as
    hmd_nlist_build_head_list.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
-   (different streams or host threads) race and must be serialised by the caller. */
+   (different streams or host threads) race and must be serialised by the caller.  The array used is the
+   copy of the current GPU; a non-null stream must belong to that GPU (HMD_ERR_INVALID_ARGUMENT otherwise).
+   The FIRST call on a GPU looks the array's address up (a lock and one hipGetSymbolAddress): make it
+   outside graph capture; later calls only launch kernels. */
 int hmd_nlist_build_head_list_noalloc(const hmd_head_list_args_t* args, void* stream);
 
 /* Replaces gpu_compute_nlist_binned (hoomd/md/NeighborListGPUBinned.cuh:35-62,

@@ -30,7 +30,12 @@ def build_kg(hoomd, decomposition, n, steps, sorter):
     return sim, cell, wca, thermo
 
 
-def build(hoomd, decomposition, n, steps, sorter):
+def build_tail(hoomd, decomposition, n, steps, sorter):
+    """The LJ liquid without an energy shift and with the long-range (tail) correction of energy and pressure."""
+    return build(hoomd, decomposition, n, steps, sorter, tail=True)
+
+
+def build(hoomd, decomposition, n, steps, sorter, tail=False):
     import lj_liquid
     snap = lj_liquid.make_snapshot(hoomd, n, kT=1.5, seed=11)
     rng = np.random.default_rng(2)
@@ -42,7 +47,8 @@ def build(hoomd, decomposition, n, steps, sorter):
     else:
         sim.create_state_from_snapshot(snap, domain_decomposition=decomposition)
     cell = hoomd.md.nlist.Cell(buffer=0.4)
-    lj = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.5, mode="shift")
+    lj = hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.5, mode="none", tail_correction=True) if tail else \
+        hoomd.md.pair.LJ(nlist=cell, default_r_cut=2.5, mode="shift")
     lj.params[("A", "A")] = dict(epsilon=1.0, sigma=1.0)
     method = hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All())
     sim.operations.integrator = hoomd.md.Integrator(dt=0.005, methods=[method], forces=[lj])
@@ -71,7 +77,7 @@ def main():
         from hoomd_amd import comm
         dd = comm.DomainDecomposition(grid=grid)
     torch.cuda.set_device(0)
-    sim, cell, lj, thermo = (build_kg if workload == "kg" else build)(hoomd, dd, n, steps, sorter)
+    sim, cell, lj, thermo = {"kg": build_kg, "tail": build_tail}.get(workload, build)(hoomd, dd, n, steps, sorter)
     sim.run(0)
     if dd is not None:
         # a stuck run says which stream holds unfinished work before the launcher's limit ends it
@@ -91,8 +97,10 @@ def main():
         done.set()
     s = sim.state.get_snapshot()
     dof = thermo.degrees_of_freedom  # collective under domain decomposition: every rank asks
+    pair_energy = lj.energy          # likewise (summed over ranks, hoomd/ForceCompute.cc:196-226)
+    pressure = thermo.pressure
     stats = dict(N_local=int(sim._sysdef.getParticleData().N), n_ghosts=int(sim._sysdef.getParticleData().n_ghosts), builds=int(cell.num_builds),
-                 overlapped=int(cell._cpp_obj.num_overlapped))
+                 overlapped=int(cell._cpp_obj.num_overlapped), additional_energy=float(lj.additional_energy))
     if dd is not None:
         ex = dd.communicator
         stats.update(migrated_out=int(ex.n_migrated_out), migrated_in=int(ex.n_migrated_in), vote_exchanges=int(ex.n_vote_exchanges),
@@ -104,7 +112,7 @@ def main():
         allstats = [stats]
     if rank == 0:
         np.savez(out, position=s.particles.position, velocity=s.particles.velocity, image=s.particles.image, e0=e0, e1=e1,
-                 dof=dof, N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
+                 dof=dof, pair_energy=pair_energy, pressure=pressure, additional_energy=[a["additional_energy"] for a in allstats], N_local=[a["N_local"] for a in allstats], n_ghosts=[a["n_ghosts"] for a in allstats],
                  builds=[a["builds"] for a in allstats], migrated=[a.get("migrated_out", 0) for a in allstats],
                  vote_exchanges=[a.get("vote_exchanges", 0) for a in allstats], overlapped=[a["overlapped"] for a in allstats],
                  fixed_migrate=[a.get("fixed_migrate", 0) for a in allstats], slot_rows=[a.get("slot_rows", 0) for a in allstats],

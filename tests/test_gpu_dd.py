@@ -105,18 +105,65 @@ def test_bonded_melt_under_decomposition_matches_single_domain(tmp_path, world, 
     assert sum(b["migrated"]) > 0
 
 
-def test_one_rank_decomposition_over_rccl_at_production_priority():
-    """The production transport and stream priority, as far as one GPU allows: one rank (nothing to exchange: the
-    migration, ghost and vote collectives run empty), RCCL collectives on the high-priority exchange stream."""
+def test_tail_correction_under_decomposition_uses_global_counts(tmp_path):
+    """Long-range corrections (hoomd/md/PotentialPair.h:283-337): from the global particle counts, added once -- the
+    decomposed run reports the single-domain energy and pressure, and only rank 0 carries the correction."""
+    n, steps = (16, 16, 16), 20
+    ref, out = str(tmp_path / "ref.npz"), str(tmp_path / "dd.npz")
+    launch("_dd_worker.py", 1, [1, 1, 1, ref] + list(n) + [steps, 0, "tail"], timeout=60)
+    launch("_dd_worker.py", 2, [1, 1, 2, out] + list(n) + [steps, 0, "tail"], timeout=60)
+    a, b = np.load(ref), np.load(out)
+    N = n[0] * n[1] * n[2]
+    V = N / 0.84
+    # closed form for one type (hoomd/md/EvaluatorPairLJ.h:213-248): 2 pi N rho * 4 eps (sigma^12 / (9 rc^9) - sigma^6 / (3 rc^3))
+    expected = 2 * np.pi * N * (N / V) * 4 * (1 / (9 * 2.5 ** 9) - 1 / (3 * 2.5 ** 3))
+    assert np.isclose(a["additional_energy"][0], expected, rtol=1e-12)
+    assert np.isclose(b["additional_energy"][0], expected, rtol=1e-12) and b["additional_energy"][1] == 0.0
+    assert np.isclose(a["pair_energy"], b["pair_energy"], rtol=1e-9)
+    assert np.allclose(a["e0"], b["e0"], rtol=1e-11) and np.allclose(a["e1"], b["e1"], rtol=1e-7)
+    assert np.isclose(a["pressure"], b["pressure"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("priority", ["normal", "high"])
+def test_one_rank_decomposition_over_rccl(priority):
+    """The production transport, as far as one GPU allows: one rank (nothing to exchange: the migration, ghost and vote
+    collectives run empty), RCCL collectives on the exchange stream -- at normal priority (the default) and at high
+    priority (HOOMD_AMD_COMM_PRIORITY=high)."""
     import json
     import subprocess
     root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_PORT="29533")
+    env.pop("HOOMD_AMD_COMM_PRIORITY", None)
+    if priority == "high":
+        env["HOOMD_AMD_COMM_PRIORITY"] = "high"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dd", "--lattice", "40x40x40", "--equil", "400",
-                        "--warmup", "20", "--steps", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=140,
-                       env=dict(os.environ, MASTER_PORT="29533"))
+                        "--warmup", "20", "--steps", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=140, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     d = out["config"]["decomposition"]
-    assert d["backend"] == "nccl" and d["exchange_stream_high_priority"] is True
+    assert d["backend"] == "nccl" and d["exchange_stream_high_priority"] is (priority == "high")
     assert out["config"]["rebuilds_in_timed_region"] > 10 and 60 < out["config"]["mean_listed_neighbors"] < 110
     assert out["value"] > 0
+
+
+@pytest.mark.parametrize("scaling,lattice,total", [("weak", "24x24x24", 2 * 24 ** 3), ("strong", "24x48x24", 24 * 48 * 24)])
+def test_bench_starts_its_own_ranks(scaling, lattice, total):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts two fresh ranks (here sharing
+    GPU 0 over gloo, the rehearsal form), relays rank 0's line; --scaling decides whether the lattice is per GPU or the
+    whole system's."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling, "--lattice", lattice,
+                        "--equil", "300", "--warmup", "20", "--steps", "100", "--no-cpu-baseline", "--launch-timeout", "150"],
+                       capture_output=True, text=True, timeout=170, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["N"] == total
+    assert out["config"]["domain_grid"] == ([1, 1, 2] if scaling == "weak" else [1, 2, 1])
+    d = out["config"]["decomposition"]
+    assert d["backend"] == "gloo" and d["ghosts_rank0"] > 0 and d["exchange_stream_high_priority"] is False
+    assert out["config"]["rebuilds_in_timed_region"] > 5 and out["value"] > 0

@@ -110,6 +110,28 @@ def test_pair_list_of_the_7x7x7_lattice(hoomd):
     arrays = cell.cpu_local_nlist_arrays
     assert np.all(arrays["n_neigh"] == 6) and not arrays["half_nlist"]
     assert cell.dimensions == (6, 6, 6)
+    # the same buffers on the device, zero-copy (hoomd/md/pytest/test_nlist.py:430-573: gpu_local_nlist_arrays)
+    import torch
+    with cell.gpu_local_nlist_arrays as data:
+        assert not data.half_nlist
+        # (unsigned 64- and 32-bit buffers, seen through signed views of the same width for the index arithmetic)
+        head = torch.as_tensor(data.head_list, device="cuda").view(torch.int64)
+        nn = torch.as_tensor(data.n_neigh, device="cuda").view(torch.int32)
+        nl = torch.as_tensor(data.nlist, device="cuda").view(torch.int32)
+        assert head.data_ptr() == cell._cpp_obj.head_list_ptr and nl.data_ptr() == cell._cpp_obj.nlist_ptr
+        assert head.shape == (343,) and nn.shape == (343,) and nl.numel() >= int((head[-1] + nn[-1].to(head.dtype)).item())
+        assert np.array_equal(head.cpu().numpy().view(np.uint64), arrays["head_list"])
+        assert np.array_equal(nn.cpu().numpy().view(np.uint32), arrays["n_neigh"])
+        # pairs (i < j) built on the device from the three buffers are the reference's list
+        i = torch.repeat_interleave(torch.arange(343, device="cuda"), nn.to(torch.int64))
+        offs = torch.arange(i.numel(), device="cuda") - torch.repeat_interleave(torch.cumsum(nn.to(torch.int64), 0) - nn.to(torch.int64), nn.to(torch.int64))
+        j = nl.to(torch.int64)[head.to(torch.int64)[i] + offs]
+        pairs = {(int(a), int(b)) for a, b in zip(i.tolist(), j.tolist()) if a < b}
+        assert pairs == {tuple(sorted(p)) for p in local.tolist()}
+        with pytest.raises(RuntimeError):
+            cell.gpu_local_nlist_arrays
+    with pytest.raises(RuntimeError):
+        data.head_list  # the views die with the block
 
 
 @pytest.mark.parametrize("mode", ["none", "shift", "xplor"])

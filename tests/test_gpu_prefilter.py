@@ -87,12 +87,11 @@ def test_prefiltered_build_equals_exact_test(K, A, L, seed):
         return orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
                                  nl["head"].cpu().numpy().view(np.uint64)[:N])
 
-    # ("exact": the general kernel, which serves several particle types and the body filter.  It shifts the candidates
-    # of a periodic image once when it loads them, so across the boundary its difference is p_i - (p_j + L) where the
-    # CPU path has (p_i - p_j) - L: the last bit of the squared distance can differ, hence the engineered pairs are
-    # only required of the pre-test kernel, whose exact test repeats the CPU arithmetic.)
+    # "exact": the general kernel (several particle types, body filter, triclinic boxes), chosen here by the
+    # environment switch.  It shifts the candidates of a periodic image once when it loads them and decides pairs
+    # whose squared distance comes within rounding of r_list^2 again with the CPU path's (p_i - p_j) - L.
     results = {}
-    for mode in ("pretest",):
+    for mode in ("pretest", "exact"):
         if mode == "exact":
             os.environ["HOOMD_AMD_NLIST_EXACT_ONLY"] = "1"
         try:
@@ -219,3 +218,89 @@ def test_block_build_for_sparse_cells(K, A, L, seed, excl):
     finally:
         os.environ.pop("HOOMD_AMD_NLIST_NO_BLOCK_BUILD", None)
     assert np.array_equal(rows2["n_neigh"].cpu().numpy(), rows["n_neigh"].cpu().numpy())
+
+
+def _wrap_triclinic(xyz, L, xy, xz, yz):
+    """Into the box spanned by a1 = (Lx, 0, 0), a2 = (xy Ly, Ly, 0), a3 = (xz Lz, yz Lz, Lz), centred on the origin."""
+    h = np.array([[L[0], xy * L[1], xz * L[2]], [0.0, L[1], yz * L[2]], [0.0, 0.0, L[2]]])
+    f = np.linalg.solve(h, xyz.T).T + 0.5
+    f -= np.floor(f)
+    f = np.clip(f, 1e-9, 1.0 - 1e-9)
+    return (h @ (f - 0.5).T).T
+
+
+@pytest.mark.parametrize("case", ["three_types", "body_filter", "triclinic", "two_cells_wide", "triclinic_two_types"])
+def test_general_build_decides_pairs_at_r_list_like_the_cpu_path(K, A, case):
+    """The build kernel that serves everything the pre-test kernel does not -- three or more particle types, the body
+    filter, triclinic boxes (images of adjacent cells fixed up front) and grids with fewer than three cells along a
+    periodic direction (minimum image per pair) -- on pairs engineered onto r_list, one ulp to either side of it and
+    through 1e-14 ... 1e-5 around it, many of them across periodic faces: the sets are the CPU oracle's
+    (hoomd/md/NeighborListBinned.cc:150-157 with hoomd/BoxDim.h:306-372), bit for bit."""
+    r_buff = 0.4
+    tilt = (0.0, 0.0, 0.0)
+    L = (21.0, 18.0, 23.0)
+    body = None
+    nt = 1
+    r_cut = np.array([[2.5]])
+    if case == "three_types":
+        nt = 3
+        r_cut = np.array([[2.5, 2.0, 2.2], [2.0, 1.8, -1.0], [2.2, -1.0, 2.4]])
+    elif case == "triclinic":
+        tilt = (0.3, -0.2, 0.15)
+    elif case == "triclinic_two_types":
+        nt, tilt = 2, (-0.25, 0.1, 0.35)
+        r_cut = np.array([[2.5, 2.1], [2.1, 1.9]])
+    elif case == "two_cells_wide":
+        L = (21.0, 18.0, 6.5)   # two cells along z: every cell sees both images of its z neighbor
+    r_list = np.where(r_cut > 0, r_cut + r_buff, 1.7)
+    n_free, n_pairs = int(0.6 * L[0] * L[1] * L[2]), 4000
+    rng = np.random.default_rng(40 + ["three_types", "body_filter", "triclinic", "two_cells_wide", "triclinic_two_types"].index(case))
+    typ = rng.integers(0, nt, n_free + n_pairs)
+    xyz = _system(11 + len(case), L, n_free, n_pairs, r_list if nt > 1 else float(r_list[0, 0]), typ if nt > 1 else None)
+    if any(tilt):
+        xyz = _wrap_triclinic(xyz, L, *tilt)
+    N = len(xyz)
+    if case == "body_filter":
+        # rigid-body ids: free particles in bodies of three, every fourth engineered partner in its source's body
+        body = np.full(N, 0xFFFFFFFF, dtype=np.uint32)
+        body[: n_free - n_free % 3] = np.repeat(np.arange(n_free // 3, dtype=np.uint32), 3)
+    pos = orc.pack_pos(xyz, typ if nt > 1 else np.zeros(N, dtype=int))
+    obox, gbox = orc.Box.from_L(*L, *tilt), A.Box.from_L(*L, *tilt)
+    dim = orc.cell_dimensions(obox, float(r_list.max()) if nt > 1 else 2.9)
+    assert (min(dim) >= 3) == (case != "two_cells_wide")
+    ref = orc.nlist_binned(pos, N, obox, r_cut, r_buff, storage_full=True, body=body, filter_body=body is not None)
+    ref_sets = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    # engineered pairs land on both sides of r_list^2 within rounding, also across the periodic faces
+    h = np.array([[L[0], tilt[0] * L[1], tilt[1] * L[2]], [0.0, L[1], tilt[2] * L[2]], [0.0, 0.0, L[2]]])
+    close = across = 0
+    for i in range(n_free, N, 5):
+        d = xyz[:n_free] - xyz[i]
+        f = np.linalg.solve(h, d.T).T
+        wrapped = np.rint(f)
+        d = (h @ (f - wrapped).T).T
+        r2 = np.einsum("ij,ij->i", d, d)
+        rl = r_list[typ[i], typ[:n_free]] if nt > 1 else r_list[0, 0]
+        k = np.argmin(np.abs(r2 - rl ** 2))
+        if abs(r2[k] - (rl[k] if nt > 1 else rl) ** 2) < 1e-9:
+            close += 1
+            across += bool(wrapped[k].any())
+    assert close > 50 and across > 5
+
+    pos_t = torch.from_numpy(pos).cuda()
+    body_t = torch.from_numpy(body.view(np.int32)).cuda() if body is not None else None
+    cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True, **({"body": body_t} if body is not None else {}))
+    adj = torch.as_tensor(orc.cell_adj(dim).view(np.int32), device="cuda")
+    os.environ["HOOMD_AMD_NLIST_EXACT_ONLY"] = "1"  # (one and two types would take the pre-test kernel in orthorhombic boxes)
+    try:
+        lists = [K.nlist_binned(pos_t, N, gbox, r_cut, r_buff, cl, adj, body=body_t, filter_body=body is not None)]
+        if case == "three_types":  # (tile rows exist for orthorhombic boxes)
+            tl = K.nlist_tiles(pos_t, N, gbox, r_cut, r_buff, cl, adj)
+            tl["nlist"] = K.tiles_to_rows(tl, N, gbox)
+            lists.append(tl)
+    finally:
+        os.environ.pop("HOOMD_AMD_NLIST_EXACT_ONLY", None)
+    for nl in lists:
+        assert np.array_equal(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"])
+        got = orc.neighbor_sets(nl["n_neigh"].cpu().numpy().view(np.uint32)[:N], nl["nlist"].cpu().numpy().view(np.uint32),
+                                nl["head"].cpu().numpy().view(np.uint64)[:N])
+        assert same_sets(got, ref_sets)

@@ -65,3 +65,28 @@ def test_noalloc_head_list_rejects_sizes_beyond_its_scratch():
     a.N, a.ntypes = (1 << 24) + 1, 1
     assert _abi.lib.hmd_nlist_build_head_list_noalloc(C.byref(a), None) == _abi.ERR_TOO_LARGE
     assert b"16,777,216" in _abi.lib.hmd_last_error()
+
+
+def test_noalloc_head_list_allocates_no_device_memory():
+    """hipMemGetInfo before and after: once the first call on the GPU has happened (it loads the kernels and looks the
+    array's address up), further calls leave the device's free memory where it was."""
+    from hoomd_amd import _abi
+    from hoomd_amd._abi import check, ptr
+    N = 200003
+    pos, typeid, Nmax, Nmax_t = _case(N, 2, 9)
+    head = torch.zeros(N, dtype=torch.int64, device="cuda")
+    req = torch.zeros(1, dtype=torch.int64, device="cuda")
+    a = _abi.HeadListArgs()
+    a.d_head_list, a.d_req_size_nlist, a.d_Nmax, a.d_pos = ptr(head), ptr(req), ptr(Nmax_t), ptr(pos)
+    a.N, a.ntypes = N, 2
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(_abi.lib.hmd_nlist_build_head_list_noalloc(C.byref(a), stream), "warm call")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in (N, 5000, N):
+        a.N = n
+        check(_abi.lib.hmd_nlist_build_head_list_noalloc(C.byref(a), stream), "hmd_nlist_build_head_list_noalloc")
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    expect = np.concatenate([[0], np.cumsum(Nmax[typeid])])
+    assert int(req.item()) == expect[-1] and np.array_equal(head.cpu().numpy(), expect[:-1])
