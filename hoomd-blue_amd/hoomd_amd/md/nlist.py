@@ -8,9 +8,11 @@ from ..operation import AutotunedObject
 
 class DeviceArrayView:
     """Read-only view of one of the neighbor list's device buffers (role of hoomd.data.array.HOOMDGPUArray,
-    hoomd/data/array.py): carries ``__cuda_array_interface__`` (version 2: shape, typestr, data pointer, read-only), so
-    ``torch.as_tensor(view, device="cuda")`` or ``cupy.asarray(view)`` wrap the same memory without a copy.  Valid only
-    inside the ``with`` block that handed it out."""
+    hoomd/data/array.py): carries ``__cuda_array_interface__`` (version 2: shape, typestr, data pointer), so
+    ``torch.as_tensor(view, device="cuda")`` or ``cupy.asarray(view)`` wrap the same memory without a copy.  The
+    buffers are the neighbor list's own and must not be written to (``read_only`` says so; the interface's own
+    read-only flag stays clear because torch refuses to wrap memory that carries it).  Valid only inside the ``with``
+    block that handed it out."""
 
     def __init__(self, owner, ptr, shape, typestr):
         self._owner = owner
@@ -19,7 +21,7 @@ class DeviceArrayView:
     @property
     def __cuda_array_interface__(self):
         self._owner._check()
-        return {"shape": self._shape, "typestr": self._typestr, "data": (self._ptr, True), "version": 2}
+        return {"shape": self._shape, "typestr": self._typestr, "data": (self._ptr, False), "version": 2}
 
     shape = property(lambda self: self._shape)
     dtype = property(lambda self: np.dtype(self._typestr))
