@@ -442,7 +442,8 @@ def main():
         }
         if decomposition is not None:
             out["config"]["decomposition"] = {
-                "backend": dist.get_backend(), "exchange_stream_high_priority": bool(cell._cpp_obj.comm_stream_high_priority),
+                "backend": dist.get_backend(), "transport": decomposition.communicator.transport_name, "exchange_stream_high_priority": bool(cell._cpp_obj.comm_stream_high_priority),
+                "exchange_stream_kept_after_probe": int(cell._cpp_obj.comm_stream_probe),
                 "steps_with_forces_overlapping_the_exchange": int(cell._cpp_obj.num_overlapped),
                 "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.n_vote_exchanges)}
         if world == 1 and not args.no_cpu_baseline:

@@ -730,3 +730,66 @@ extern "C" int hmd_vote_plan(const hmd_vote_plan_args_t* args, void* stream)
     hipLaunchKernelGGL(vote_plan_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, *args);
     return hmd_launch_status();
     }
+
+// ---- does a stream run beside the default stream? ----
+// HIP multiplexes its streams over a handful of hardware queues; a created stream that happens to share the default
+// stream's queue runs strictly behind whatever the default stream holds, however small its own kernels are.  The probe
+// puts a long kernel on the default stream (LDS-bound occupancy like the force kernel: half of every CU's wave slots
+// stay free) and a one-wave kernel on the candidate, queued behind an event recorded just before the long one: on a
+// queue of its own the small kernel is done after a few microseconds, on the shared queue only after the long one.
+namespace
+    {
+__global__ void __launch_bounds__(256) probe_busy_kernel(unsigned long long* d_out, unsigned long long ticks)
+    {
+    extern __shared__ unsigned long long s_probe[];
+    s_probe[threadIdx.x] = ticks;
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) // wall_clock64 counts at 100 MHz: every wave leaves after `ticks` * 10 ns
+        t = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        d_out[0] = t + s_probe[0];
+    }
+__global__ void probe_tiny_kernel(unsigned long long* d_out)
+    {
+    d_out[0] = wall_clock64();
+    }
+    } // namespace
+
+extern "C" int hmd_stream_runs_beside_default(void* stream, unsigned long long* d_scratch2, int* overlaps)
+    {
+    HMD_REQUIRE(stream && d_scratch2 && overlaps, HMD_ERR_INVALID_ARGUMENT, "hmd_stream_runs_beside_default: a created stream, two device words and overlaps are required");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t b0 = nullptr, b1 = nullptr, t1 = nullptr, ready = nullptr;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    step(hipEventCreate(&b0));
+    step(hipEventCreate(&b1));
+    step(hipEventCreate(&t1));
+    step(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    int cus = 256;
+    step(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    if (e == hipSuccess)
+        {
+        step(hipDeviceSynchronize());
+        hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, nullptr, d_scratch2);
+        step(hipEventRecord(ready, nullptr));
+        step(hipEventRecord(b0, nullptr));
+        // two generations of four workgroups per CU, 60 us each
+        hipLaunchKernelGGL(probe_busy_kernel, dim3((unsigned int)cus * 8u), dim3(256), 36 * 1024, nullptr, d_scratch2, 6000ull);
+        step(hipEventRecord(b1, nullptr));
+        step(hipStreamWaitEvent(s, ready, 0));
+        hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, s, d_scratch2 + 1);
+        step(hipEventRecord(t1, s));
+        step(hipStreamSynchronize(s));
+        step(hipDeviceSynchronize());
+        float long_ms = 0.f, tiny_ms = 0.f;
+        step(hipEventElapsedTime(&long_ms, b0, b1));
+        step(hipEventElapsedTime(&tiny_ms, b0, t1));
+        *overlaps = (e == hipSuccess && tiny_ms < 0.5f * long_ms) ? 1 : 0;
+        }
+    for (hipEvent_t ev : {b0, b1, t1, ready})
+        if (ev)
+            (void)hipEventDestroy(ev);
+    return e == hipSuccess ? hmd_launch_status() : (int)e;
+    }

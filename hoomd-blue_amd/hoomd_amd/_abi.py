@@ -278,6 +278,7 @@ _SIGNATURES = {
     "hmd_migrate_unpack": (C.c_int, [C.POINTER(MigrateUnpackArgs), vp]),
     "hmd_publish_word": (C.c_int, [vp, vp, u32, vp]),
     "hmd_publish_words": (C.c_int, [vp, u32, vp, u32, vp]),
+    "hmd_stream_runs_beside_default": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
     "hmd_update_bond_table": (C.c_int, [C.POINTER(BondTableArgs), vp]),
     "hmd_compute_bond_forces_fene": (C.c_int, [C.POINTER(BondArgs), vp, vp]),
     "hmd_compute_pair_forces_lj": (C.c_int, [C.POINTER(PairArgs), vp, vp]),

@@ -563,7 +563,7 @@ class Communicator:
         self.dd = dd
         self.sysdef = sysdef
         device = torch.device("cuda", torch.cuda.current_device())
-        self.transport = TorchTransport(dd.group, device)
+        self.transport = self._make_transport(dd, device)
         self.cpp = _cpp.CommunicatorGPU(sysdef, self.transport, dd.rank, dd.world, [int(g) for g in dd.grid], [float(v) for v in dd.glo],
                                         [float(v) for v in dd.gL])
         self.cpp.setUseVoteRows(os.environ.get("HOOMD_AMD_VOTE_ROWS", "1") != "0")
@@ -575,11 +575,47 @@ class Communicator:
             self.cpp.setGhostSlotRoom(div, pad)
         self.nlists = []
 
+    @staticmethod
+    def _make_transport(dd, device):
+        """RCCL called from C++ (``_cpp.RcclTransport``) when the process group's backend is nccl; ``TorchTransport``
+        (collectives through torch.distributed, host-staged for gloo) otherwise, when HOOMD_AMD_TRANSPORT=torch asks
+        for it, or when the RCCL communicator cannot be set up on every rank."""
+        want = os.environ.get("HOOMD_AMD_TRANSPORT", "")
+        if want not in ("", "rccl", "torch"):
+            raise ValueError("HOOMD_AMD_TRANSPORT must be 'rccl' or 'torch'")
+        if dist.get_backend(dd.group) != "nccl" or want == "torch" or not hasattr(_cpp, "RcclTransport"):
+            if want == "rccl":
+                raise RuntimeError("HOOMD_AMD_TRANSPORT=rccl needs a process group with the nccl backend")
+            return TorchTransport(dd.group, device)
+        # rank 0 makes the id, the existing group carries its 128 bytes to the others
+        box = [_cpp.RcclTransport.unique_id() if dd.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(dd.group, 0) if dd.group is not None else 0, group=dd.group)
+        transport, err = None, None
+        try:
+            transport = _cpp.RcclTransport(box[0], dd.rank, dd.world)
+        except RuntimeError as e:  # the same decision on every rank, below
+            err = str(e)
+        oks = [None] * dd.world
+        dist.all_gather_object(oks, err, group=dd.group)
+        bad = [(r, e) for r, e in enumerate(oks) if e is not None]
+        if bad:
+            if want == "rccl":
+                raise RuntimeError(f"RCCL transport: rank {bad[0][0]}: {bad[0][1]}")
+            import warnings
+            warnings.warn(f"RCCL transport not available (rank {bad[0][0]}: {bad[0][1]}); collectives go through torch.distributed")
+            return TorchTransport(dd.group, device)
+        transport.device = device
+        transport.stage = False
+        transport.side = None
+        return transport
+
     def add_nlist(self, nlist):
         self.nlists.append(nlist)
         self.cpp.addNeighborList(nlist._cpp_obj)
 
     # statistics of the exchange (tests, bench)
+    transport_name = property(lambda self: "rccl (C++: " + _cpp.RcclTransport.library_origin() + ")" if isinstance(self.transport, getattr(_cpp, "RcclTransport", ()))
+                              else "torch.distributed " + dist.get_backend(self.dd.group))
     n_migrated_out = property(lambda self: self.cpp.n_migrated_out)
     n_migrated_in = property(lambda self: self.cpp.n_migrated_in)
     n_vote_exchanges = property(lambda self: self.cpp.n_vote_exchanges)

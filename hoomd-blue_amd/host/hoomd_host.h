@@ -1146,6 +1146,12 @@ class NeighborListGPUBinned : public Compute
         {
         return m_ranks_share_gpu;
         }
+    //! which of the streams tried for the exchange was kept: 0 the first, k the (k+1)-th after k that shared the default
+    //! stream's hardware queue; -1 no probe was run (high priority, ranks sharing a GPU, switched off) or none passed
+    int getCommStreamProbe() const
+        {
+        return m_comm_stream_probe;
+        }
 
     //! time step of the last (re)build
     uint64_t getLastBuildTimestep() const
@@ -1220,6 +1226,8 @@ class NeighborListGPUBinned : public Compute
     SpeculationHook m_speculate;
     InteriorHook m_interior_hook;
     hipStream_t m_comm_stream = nullptr;
+    std::vector<hipStream_t> m_rejected_streams;
+    int m_comm_stream_probe = -1;
     hipEvent_t m_ev_ready = nullptr, m_ev_comm = nullptr;
     bool m_overlap = true;
     bool m_comm_high_priority = false, m_ranks_share_gpu = false;
@@ -1846,6 +1854,36 @@ class ExchangeTransport
         {
         throw std::runtime_error("this exchange transport has no host-side sum");
         }
+    };
+
+//! The transport on RCCL itself: ncclSend / ncclRecv groups and ncclAllReduce issued from C++ on the caller's stream
+//! (rccl_transport.cc).  One object per rank; all ranks construct it together (ncclCommInitRank is collective) from
+//! the 128-byte id that uniqueId() returned on rank 0.
+class RcclTransport : public ExchangeTransport
+    {
+    public:
+    RcclTransport(const std::string& unique_id, unsigned int rank, unsigned int world);
+    ~RcclTransport() override;
+    RcclTransport(const RcclTransport&) = delete;
+    RcclTransport& operator=(const RcclTransport&) = delete;
+    //! a fresh ncclUniqueId (rank 0 calls this and distributes the bytes)
+    static std::string uniqueId();
+    //! which librccl the calls go to ("... (already loaded in this process)" or "... (opened by hoomd_amd)")
+    static std::string libraryOrigin();
+    void allToAll(uintptr_t d_send, const std::vector<unsigned int>& send_rows, uintptr_t d_recv, const std::vector<unsigned int>& recv_rows,
+                  unsigned int row_bytes, uintptr_t stream) override;
+    void allReduceMaxWord(uintptr_t d_word, uintptr_t stream) override;
+    bool anyRank(bool local) override;
+    std::vector<double> allReduceSumHost(const std::vector<double>& v) override;
+    uint64_t n_exchanges = 0;
+    //! send this rank's own rows through ncclSend / ncclRecv to itself instead of copying them (tests: the only way to
+    //! run the send / receive calls on a machine with one GPU)
+    bool self_through_rccl = false;
+
+    private:
+    unsigned int m_rank, m_world;
+    void* m_comm = nullptr; // ncclComm_t
+    DeviceArray<double> m_words;
     };
 
 class CommunicatorGPU : public Communicator

@@ -216,6 +216,16 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("beginRebuildVote", &Communicator::beginRebuildVote)
         .def("endRebuildVote", &Communicator::endRebuildVote);
     py::class_<ExchangeTransport, PyExchangeTransport, std::shared_ptr<ExchangeTransport>>(m, "ExchangeTransport").def(py::init<>());
+    py::class_<RcclTransport, ExchangeTransport, std::shared_ptr<RcclTransport>>(m, "RcclTransport", py::dynamic_attr())
+        .def(py::init([](py::bytes id, unsigned int rank, unsigned int world) { return std::make_shared<RcclTransport>(std::string(id), rank, world); }))
+        .def_static("unique_id", []() { return py::bytes(RcclTransport::uniqueId()); })
+        .def_static("library_origin", &RcclTransport::libraryOrigin)
+        .def("allToAll", &RcclTransport::allToAll)
+        .def("allReduceMaxWord", &RcclTransport::allReduceMaxWord)
+        .def("anyRank", &RcclTransport::anyRank)
+        .def("allReduceSumHost", &RcclTransport::allReduceSumHost)
+        .def_readonly("n_exchanges", &RcclTransport::n_exchanges)
+        .def_readwrite("self_through_rccl", &RcclTransport::self_through_rccl);
     py::class_<CommunicatorGPU, Communicator, std::shared_ptr<CommunicatorGPU>>(m, "CommunicatorGPU")
         .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<ExchangeTransport>, unsigned int, unsigned int, std::array<unsigned int, 3>,
                       std::array<double, 3>, std::array<double, 3>>())
@@ -336,6 +346,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)
         .def_property_readonly("num_overlapped", &NeighborListGPUBinned::getNumOverlapped)
         .def_property("comm_stream_high_priority", &NeighborListGPUBinned::getCommStreamHighPriority, &NeighborListGPUBinned::setCommStreamHighPriority)
+        .def_property_readonly("comm_stream_probe", &NeighborListGPUBinned::getCommStreamProbe)
         .def_property("ranks_share_gpu", &NeighborListGPUBinned::getRanksShareGPU, &NeighborListGPUBinned::setRanksShareGPU)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)
         .def("getStorageMode", &NeighborListGPUBinned::getStorageMode)

@@ -60,6 +60,8 @@ NeighborListGPUBinned::~NeighborListGPUBinned()
         {
         (void)hipStreamSynchronize(m_comm_stream);
         (void)hipStreamDestroy(m_comm_stream);
+        for (hipStream_t r : m_rejected_streams)
+            (void)hipStreamDestroy(r);
         (void)hipEventDestroy(m_ev_ready);
         (void)hipEventDestroy(m_ev_comm);
         }
@@ -286,6 +288,32 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
                 else if (prio && std::string(prio) == "high" && !m_ranks_share_gpu)
                     high = true;
                 hipCheck(hipStreamCreateWithPriority(&m_comm_stream, hipStreamNonBlocking, high ? greatest : 0), "hipStreamCreateWithPriority");
+                // A created stream may land on the hardware queue of the default stream and then runs strictly behind
+                // the force kernel it is meant to run beside.  With a GPU of its own the process tries a few streams
+                // and keeps the first one whose kernels do run beside the default stream's
+                // (hmd_stream_runs_beside_default); the rejected ones are kept until the end so that the runtime does
+                // not hand their queue out again.  HOOMD_AMD_COMM_STREAM_PROBE=0 takes the first stream as it comes.
+                const char* probe_env = std::getenv("HOOMD_AMD_COMM_STREAM_PROBE");
+                m_comm_stream_probe = -1;
+                if (!high && !m_ranks_share_gpu && !(probe_env && std::string(probe_env) == "0"))
+                    {
+                    DeviceArray<unsigned long long> words;
+                    words.resize(2, false);
+                    for (int attempt = 0; attempt < 5; attempt++)
+                        {
+                        int overlaps = 0;
+                        abiCheck(hmd_stream_runs_beside_default(m_comm_stream, words.get(), &overlaps), "hmd_stream_runs_beside_default");
+                        if (overlaps)
+                            {
+                            m_comm_stream_probe = attempt;
+                            break;
+                            }
+                        if (attempt == 4)
+                            break; // none of them: keep the last
+                        m_rejected_streams.push_back(m_comm_stream);
+                        hipCheck(hipStreamCreateWithPriority(&m_comm_stream, hipStreamNonBlocking, 0), "hipStreamCreateWithPriority");
+                        }
+                    }
                 hipCheck(hipEventCreateWithFlags(&m_ev_ready, hipEventDisableTiming), "hipEventCreateWithFlags");
                 hipCheck(hipEventCreateWithFlags(&m_ev_comm, hipEventDisableTiming), "hipEventCreateWithFlags");
                 }

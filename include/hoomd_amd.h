@@ -182,6 +182,13 @@ int hmd_publish_word(const unsigned int* d_word, unsigned long long* d_published
 /* The same for n <= 64 consecutive words: d_published[k] = (stamp << 32 | d_words[k]).  Used for the overflow
    conditions of the cell list and the neighbor list, which the reference reads back with a blocking copy
    (hoomd/CellListGPU.cc:150-170, hoomd/md/NeighborListGPU.cc checkConditions). */
+/* Does `stream` (a created stream of the current GPU) run beside the default stream, or behind it?  HIP maps its
+   streams onto a few hardware queues, and one that shares the default stream's queue cannot overlap with it.  Runs a
+   120 us probe (a long kernel on the default stream, a one-wave kernel on `stream`) and sets *overlaps to 1 when the
+   small kernel finished in the first half of the long one.  d_scratch2: two 64-bit device words.  Synchronises the
+   device; for set-up time.  No counterpart in the reference (its communicator finishes the ghost update before
+   the forces start, hoomd/Communicator.cc:1544-1549); used to choose the stream of the halo exchange. */
+int hmd_stream_runs_beside_default(void* stream, unsigned long long* d_scratch2, int* overlaps);
 int hmd_publish_words(const unsigned int* d_words, unsigned int n, unsigned long long* d_published, unsigned int stamp, void* stream);
 
 /* Replaces gpu_nlist_build_head_list (hoomd/md/NeighborListGPU.cu:415-456):

@@ -124,6 +124,20 @@ def test_tail_correction_under_decomposition_uses_global_counts(tmp_path):
     assert np.isclose(a["pressure"], b["pressure"], rtol=1e-7)
 
 
+def test_one_rank_decomposition_through_torch_distributed_when_asked():
+    """HOOMD_AMD_TRANSPORT=torch: the collectives of the same run go through torch.distributed (the path every gloo
+    test uses, here on the nccl backend)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_PORT="29534", HOOMD_AMD_TRANSPORT="torch")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dd", "--lattice", "40x40x40", "--equil", "400",
+                        "--warmup", "20", "--steps", "200", "--no-cpu-baseline"], capture_output=True, text=True, timeout=140, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])["config"]["decomposition"]
+    assert d["backend"] == "nccl" and d["transport"] == "torch.distributed nccl"
+
+
 @pytest.mark.parametrize("priority", ["normal", "high"])
 def test_one_rank_decomposition_over_rccl(priority):
     """The production transport, as far as one GPU allows: one rank (nothing to exchange: the migration, ghost and vote
@@ -142,6 +156,10 @@ def test_one_rank_decomposition_over_rccl(priority):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     d = out["config"]["decomposition"]
     assert d["backend"] == "nccl" and d["exchange_stream_high_priority"] is (priority == "high")
+    # RCCL is called from the C++ communicator, through the copy of the library the process already holds
+    assert d["transport"].startswith("rccl (C++") and "already loaded" in d["transport"]
+    # at normal priority a stream that runs beside the default stream was found by the probe
+    assert (d["exchange_stream_kept_after_probe"] >= 0) == (priority == "normal")
     assert out["config"]["rebuilds_in_timed_region"] > 10 and 60 < out["config"]["mean_listed_neighbors"] < 110
     assert out["value"] > 0
 
@@ -167,3 +185,33 @@ def test_bench_starts_its_own_ranks(scaling, lattice, total):
     d = out["config"]["decomposition"]
     assert d["backend"] == "gloo" and d["ghosts_rank0"] > 0 and d["exchange_stream_high_priority"] is False
     assert out["config"]["rebuilds_in_timed_region"] > 5 and out["value"] > 0
+
+
+def test_rccl_transport_issues_send_and_receive_from_cpp():
+    """The C++ transport's ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a created stream, as far as one GPU
+    allows: a one-rank communicator whose own rows are sent through RCCL to itself (in a run they are copied), with
+    unequal row sizes; the device-to-device copy path; the reductions of a one-rank group."""
+    import torch
+    from hoomd_amd import _hoomd_amd as cpp
+    t = cpp.RcclTransport(cpp.RcclTransport.unique_id(), 0, 1)
+    assert "librccl" in cpp.RcclTransport.library_origin()
+    s = torch.cuda.Stream()
+    for row_bytes, rows in ((32, 1000), (144, 37), (4, 1)):
+        src = torch.randint(0, 255, (rows * row_bytes,), dtype=torch.uint8, device="cuda")
+        for through in (True, False):
+            dst = torch.zeros_like(src)
+            t.self_through_rccl = through
+            torch.cuda.synchronize()
+            t.allToAll(src.data_ptr(), [rows], dst.data_ptr(), [rows], row_bytes, s.cuda_stream)
+            s.synchronize()
+            assert torch.equal(src, dst), (row_bytes, rows, through)
+    t.allToAll(0, [0], 0, [0], 32, s.cuda_stream)  # nothing to move: no call at all
+    w = torch.tensor([7], dtype=torch.int32, device="cuda")
+    t.allReduceMaxWord(w.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert int(w.item()) == 7 and t.anyRank(True) is True and t.anyRank(False) is False
+    assert t.allReduceSumHost([1.5, -2.0]) == [1.5, -2.0]
+    with pytest.raises(ValueError):
+        t.allToAll(src.data_ptr(), [1, 2], dst.data_ptr(), [1], 4, 0)
+    with pytest.raises(ValueError):
+        cpp.RcclTransport(b"short", 0, 1)

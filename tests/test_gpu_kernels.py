@@ -1053,3 +1053,24 @@ def test_sort_keys(K, A, n, bits):
         keys = (rng.integers(0, 2**(bits - 32), n, dtype=np.int64) << 32) | rng.integers(0, 2**21, n, dtype=np.int64)
     out = K.sort_keys(torch.from_numpy(keys).cuda(), bits).cpu().numpy()
     assert np.array_equal(out, np.sort(keys))
+
+
+def test_probe_tells_streams_that_run_beside_the_default_stream_from_those_behind_it():
+    """hmd_stream_runs_beside_default: of a handful of created streams at least one has a hardware queue of its own
+    (its one-wave kernel finishes while the default stream's long kernel runs); the answer for one stream is stable."""
+    import ctypes as C
+    from hoomd_amd import _abi
+    words = torch.zeros(2, dtype=torch.int64, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    answers = []
+    for s in streams:
+        got = []
+        for _ in range(2):
+            o = C.c_int(-1)
+            _abi.check(_abi.lib.hmd_stream_runs_beside_default(C.c_void_p(s.cuda_stream), _abi.ptr(words), C.byref(o)), "probe")
+            got.append(o.value)
+        assert got[0] == got[1] and got[0] in (0, 1)
+        answers.append(got[0])
+    assert sum(answers) >= 1
+    o = C.c_int(-1)
+    assert _abi.lib.hmd_stream_runs_beside_default(None, _abi.ptr(words), C.byref(o)) == _abi.ERR_INVALID_ARGUMENT
