@@ -16,6 +16,31 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build the HIP kernel library first "
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C hoomd-blue_amd/csrc)")
 
+
+
+def _share_the_hip_runtime_with_torch():
+    """PyTorch's ROCm wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so, the same SONAME as the
+    system's) and ask for it by a name the dynamic loader does not match against an already loaded system copy: with
+    this library loaded first and torch second, the process would hold two HIP runtimes, and device pointers, streams
+    and RCCL communicators of one mean nothing to the other.  Loading torch's copy first makes everything that follows
+    -- this library, the host module, torch itself -- resolve to that one runtime.  Without an installed torch the
+    system's runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_share_the_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 NO_BODY = 0xFFFFFFFF

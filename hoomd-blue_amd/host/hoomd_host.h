@@ -1071,7 +1071,7 @@ class NeighborListGPUBinned : public Compute
         }
     hmd_tile_geom_t getTileGeom() const;
     //! copy the current positions (owned and ghost) into cell-list slot order for the tile force kernel
-    void refreshTilePositions();
+    void refreshTilePositions(hipStream_t stream = nullptr);
     void offerFusedPass(hmd_fused_step_args_t& a, uint64_t timestep);
     //! the same offer to a pass that rides on the force kernel of the tile path: the new positions go to the second
     //! slot-ordered buffer (the kernel is still staging from the first); false when the tile path is not in use
@@ -1089,7 +1089,8 @@ class NeighborListGPUBinned : public Compute
     //! queue work that is only valid for a fresh list, predicated on the flag.
     //! (time step, device word, value that means "stale", where to publish the word for the host, stamp):
     //! queues the consumer's kernel predicated on the word; true when a kernel that publishes was queued
-    typedef std::function<bool(uint64_t, const unsigned int*, unsigned int, unsigned long long*, unsigned int)> SpeculationHook;
+    //! (time step, predicate word, value that switches the launch off, where to publish the word, stamp, stream to launch on)
+    typedef std::function<bool(uint64_t, const unsigned int*, unsigned int, unsigned long long*, unsigned int, hipStream_t)> SpeculationHook;
     void setSpeculationHook(SpeculationHook h)
         {
         m_speculate = h;
@@ -1114,6 +1115,14 @@ class NeighborListGPUBinned : public Compute
     bool getOverlapEnabled() const
         {
         return m_overlap;
+        }
+    void setBoundaryOnCommStream(bool b)
+        {
+        m_boundary_on_comm_stream = b;
+        }
+    bool getBoundaryOnCommStream() const
+        {
+        return m_boundary_on_comm_stream;
         }
     //! number of time steps whose interior blocks ran during the halo exchange
     uint64_t getNumOverlapped() const
@@ -1230,6 +1239,8 @@ class NeighborListGPUBinned : public Compute
     int m_comm_stream_probe = -1;
     hipEvent_t m_ev_ready = nullptr, m_ev_comm = nullptr;
     bool m_overlap = true;
+    //! the blocks that see ghosts are launched on the exchange's stream (beside the interior launch) rather than behind it
+    bool m_boundary_on_comm_stream = true;
     bool m_comm_high_priority = false, m_ranks_share_gpu = false;
     uint64_t m_n_overlapped = 0;
     WordReadback m_readback;

@@ -346,6 +346,7 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def_property("overlap", &NeighborListGPUBinned::getOverlapEnabled, &NeighborListGPUBinned::setOverlapEnabled)
         .def_property_readonly("num_overlapped", &NeighborListGPUBinned::getNumOverlapped)
         .def_property("comm_stream_high_priority", &NeighborListGPUBinned::getCommStreamHighPriority, &NeighborListGPUBinned::setCommStreamHighPriority)
+        .def_property("boundary_on_comm_stream", &NeighborListGPUBinned::getBoundaryOnCommStream, &NeighborListGPUBinned::setBoundaryOnCommStream)
         .def_property_readonly("comm_stream_probe", &NeighborListGPUBinned::getCommStreamProbe)
         .def_property("ranks_share_gpu", &NeighborListGPUBinned::getRanksShareGPU, &NeighborListGPUBinned::setRanksShareGPU)
         .def("setStorageMode", &NeighborListGPUBinned::setStorageMode)

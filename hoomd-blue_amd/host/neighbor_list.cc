@@ -339,12 +339,18 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
                 // the exchange's stream hands the vote to the host as soon as it is known, long before the
                 // default stream gets to the remaining blocks
                 abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, m_comm_stream), "hmd_publish_word");
+                // The blocks that see ghosts follow on the exchange's own stream, predicated on the vote: they start
+                // as soon as the ghosts are in place and run beside the last workgroups of the interior launch, instead
+                // of as a launch of their own behind it (two kernel tails one after the other).  The default stream
+                // goes on when both are done.
+                if (m_speculate && m_boundary_on_comm_stream)
+                    m_speculate(timestep, d_word, m_checkn, nullptr, 0, m_comm_stream);
                 hipCheck(hipEventRecord(m_ev_comm, m_comm_stream), "hipEventRecord");
                 hipCheck(hipStreamWaitEvent(nullptr, m_ev_comm, 0), "hipStreamWaitEvent");
-                if (m_speculate)
-                    m_speculate(timestep, d_word, m_checkn, nullptr, 0);
+                if (m_speculate && !m_boundary_on_comm_stream)
+                    m_speculate(timestep, d_word, m_checkn, nullptr, 0, nullptr);
                 }
-            else if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn)))
+            else if (!(m_speculate && m_speculate(timestep, d_word, m_checkn, d_pub, m_checkn, nullptr)))
                 abiCheck(hmd_publish_word(d_word, d_pub, m_checkn, nullptr), "hmd_publish_word");
             const unsigned long long v = pollStampedWord(hv, m_checkn, "rebuild vote", overlapped ? m_comm_stream : nullptr);
             return (unsigned int)v == m_checkn;
@@ -357,7 +363,7 @@ bool NeighborListGPUBinned::distanceCheck(uint64_t timestep)
         {
         unsigned long long* d_pub = reinterpret_cast<unsigned long long*>(m_h_words.deviceView() + 16);
         // only on the consumer's own path (compute): nothing else touches the particles before the forces
-        if (!(m_speculate && m_in_compute && m_speculate(timestep, m_flag.get(), checkn, d_pub, checkn)))
+        if (!(m_speculate && m_in_compute && m_speculate(timestep, m_flag.get(), checkn, d_pub, checkn, nullptr)))
             abiCheck(hmd_publish_word(m_flag.get(), d_pub, checkn, nullptr), "hmd_publish_word");
         }
     else
@@ -668,7 +674,7 @@ bool NeighborListGPUBinned::getInteriorBlockWindow(uint64_t timestep, unsigned i
     return true;
     }
 
-void NeighborListGPUBinned::refreshTilePositions()
+void NeighborListGPUBinned::refreshTilePositions(hipStream_t stream)
     {
     const unsigned int N = m_pdata->getN(), ng = m_pdata->getNGhosts();
     // the build of this time step wrote every slot, ghosts included
@@ -678,8 +684,8 @@ void NeighborListGPUBinned::refreshTilePositions()
     const unsigned int first = (m_cpos_tstep == m_compute_tstep) ? N : 0u;
     if (first == N && ng == 0)
         return;
-    ScopedKernelTimer t("tile_refresh");
-    abiCheck(hmd_tile_refresh(m_pdata->pos() + first, m_slot_of.get() + first, m_cpos.get(), N + ng - first, nullptr), "hmd_tile_refresh");
+    ScopedKernelTimer t("tile_refresh", stream);
+    abiCheck(hmd_tile_refresh(m_pdata->pos() + first, m_slot_of.get() + first, m_cpos.get(), N + ng - first, stream), "hmd_tile_refresh");
     }
 
 // can this build write tile rows?  (no body filter, 3D, grid and occupancy within the tile limits; exclusions are

@@ -23,11 +23,12 @@ template<class evaluator> class PotentialPairGPU : public PotentialPair<evaluato
     PotentialPairGPU(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<NeighborList> nlist) : PotentialPair<evaluator>(sysdef, nlist)
         {
         this->m_nlist->setSpeculationHook(
-            [this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale, unsigned long long* d_published, unsigned int stamp)
+            [this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale, unsigned long long* d_published, unsigned int stamp, hipStream_t stream)
             {
             m_spec_tstep = timestep;
-            // the interior blocks of this step may already be running on the side stream
-            return launchKernel(d_flag, stale, d_published, stamp, m_interior_tstep == timestep ? 2u : 0u);
+            // the interior blocks of this step may already be running on the default stream: then this launch takes the
+            // other blocks, on the stream the halo exchange ran on
+            return launchKernel(d_flag, stale, d_published, stamp, m_interior_tstep == timestep ? 2u : 0u, stream);
             });
         this->m_nlist->setInteriorHook([this](uint64_t timestep, const unsigned int* d_flag, unsigned int stale)
                                        { return launchInterior(timestep, d_flag, stale); });
@@ -86,7 +87,7 @@ template<class evaluator> class PotentialPairGPU : public PotentialPair<evaluato
     uint64_t m_rider_tstep = ~0ull; // time step whose queued kernel carries the integrator's half steps
     //! part: 0 every particle; 1 the blocks of tiles that see no ghosts; 2 the other blocks
     bool launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published = nullptr, unsigned int stamp = 0,
-                      unsigned int part = 0);
+                      unsigned int part = 0, hipStream_t stream = nullptr);
     // Queue the tile blocks that see no ghosts, predicated on the local result of the distance check, before the halo
     // exchange is queued (on another stream): they run while the ghost positions travel.  When another rank votes for
     // a rebuild their result is simply overwritten by the launch that follows the rebuild.
@@ -111,7 +112,7 @@ template<class evaluator> class PotentialPairGPU : public PotentialPair<evaluato
 
 template<class evaluator>
 bool PotentialPairGPU<evaluator>::launchKernel(const unsigned int* d_skip_flag, unsigned int skip_value, unsigned long long* d_published,
-                                               unsigned int stamp, unsigned int part)
+                                               unsigned int stamp, unsigned int part, hipStream_t stream)
     {
     using namespace hoomd_amd;
     auto& nlist = this->m_nlist;
@@ -126,6 +127,7 @@ bool PotentialPairGPU<evaluator>::launchKernel(const unsigned int* d_skip_flag, 
     kernel::pair_args_t pa;
     std::memset(&pa, 0, sizeof(pa));
     hmd_pair_args_t& a = pa.args;
+    pa.stream = stream;
     a.d_force = this->m_force.get();
     a.d_virial = this->m_virial.get();
     a.virial_pitch = this->m_virial_pitch;
@@ -170,7 +172,7 @@ bool PotentialPairGPU<evaluator>::launchKernel(const unsigned int* d_skip_flag, 
             }
         }
     if (tiles && part != 1) // (the interior blocks read owned particles only, whose copies are current)
-        nlist->refreshTilePositions();
+        nlist->refreshTilePositions(stream);
     hmd_tile_geom_t g;
     hmd_fused_step_args_t step;
     if (tiles)
@@ -197,7 +199,7 @@ bool PotentialPairGPU<evaluator>::launchKernel(const unsigned int* d_skip_flag, 
                 }
             }
         }
-    ScopedKernelTimer t(part == 1 ? "pair_force_interior" : (pa.step ? "pair_force_step" : "pair_force"));
+    ScopedKernelTimer t(part == 1 ? "pair_force_interior" : (pa.step ? "pair_force_step" : "pair_force"), stream);
     if (kernel::gpu_compute_pair_forces<evaluator>(pa, m_d_params.get()) != hipSuccess)
         throw std::runtime_error(std::string("gpu_compute_pair_forces<") + std::string(evaluator::getName()) + ">: " + hmd_last_error());
     return a.N != 0; // the drivers launch nothing for an empty system

@@ -86,3 +86,17 @@ def test_argument_validation_without_a_gpu():
     c = _abi.CellListArgs()
     assert _abi.lib.hmd_compute_cell_list(C.byref(c), None) == _abi.ERR_INVALID_ARGUMENT
     assert _abi.lib.hmd_gather_rows(C.c_void_p(8), C.c_void_p(16), C.c_void_p(8), 4, 7, None) == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """PyTorch's wheel carries its own copy of the HIP runtime; imported after this package it must not become a
+    second runtime in the process (device pointers, streams and RCCL communicators are shared between the two)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); %s\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(len(libs), libs)")
+    for order in ("import hoomd_amd, torch", "import torch, hoomd_amd"):
+        r = subprocess.run([sys.executable, "-c", code % (os.path.join(root, "hoomd-blue_amd"), order)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[0] == "1", (order, r.stdout)
