@@ -146,13 +146,14 @@ PYBIND11_MODULE(_hoomd_amd, m)
     m.def("poll_wait_seconds", &pollWaitSeconds, py::arg("reset") = false);
     m.def("abi_version", []() { return hmd_abi_version(); });
 
-    m.def("enable_kernel_timing", [](bool on, const std::string& only, double min_us)
+    m.def("enable_kernel_timing", [](bool on, const std::string& only, double min_us, unsigned int every)
           {
           KernelTimer::get().setFilter(only);
           KernelTimer::get().setMinMs(min_us * 1e-3);
+          KernelTimer::get().setEvery(every);
           KernelTimer::get().enable(on);
           },
-          py::arg("on"), py::arg("only") = "", py::arg("min_us") = 0.0);
+          py::arg("on"), py::arg("only") = "", py::arg("min_us") = 0.0, py::arg("every") = 1);
     m.def("reset_kernel_timing", []() { KernelTimer::get().reset(); });
     m.def("kernel_timing", []()
           {
