@@ -452,7 +452,11 @@ def main():
                 "backend": dist.get_backend(), "transport": decomposition.communicator.transport_name, "exchange_stream_high_priority": bool(cell._cpp_obj.comm_stream_high_priority),
                 "exchange_stream_kept_after_probe": int(cell._cpp_obj.comm_stream_probe),
                 "steps_with_forces_overlapping_the_exchange": int(cell._cpp_obj.num_overlapped),
-                "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.n_vote_exchanges)}
+                "ghosts_rank0": int(pdata.n_ghosts), "halo_exchanges_carrying_the_vote": int(decomposition.communicator.n_vote_exchanges),
+                # rebuild-step exchanges (migration, ghost layer) whose message sizes stayed on the device until after the
+                # exchange, and exchanges of counts that preceded a message
+                "exchanges_with_sizes_read_on_the_device": int(decomposition.communicator.n_device_count_exchanges),
+                "exchanges_of_counts": int(decomposition.communicator.n_count_exchanges)}
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "lj":
                 out["cpu_baseline"] = cpu_baseline(sim.state.get_snapshot(), args.cpu_steps)

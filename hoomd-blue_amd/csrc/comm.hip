@@ -447,6 +447,198 @@ __global__ void __launch_bounds__(MF_THREADS) migrate_fill_kernel(hmd_migrate_fi
         }
     }
 
+// ---- the same packs with their sizes read on the device ----
+// The counts a pack needs (how many particles leave, how many go to each rank; how many ghost rows go in each
+// direction) are where the kernels before it left them, in device memory.  Reading them there instead of waiting for
+// the host to fetch them and pass them back as arguments takes a round trip to the host out of each half of the
+// exchange: the host looks at the counts once, after the messages have crossed, together with the headers.
+__global__ void __launch_bounds__(256) migrate_pack_dev_kernel(hmd_migrate_pack_args_t a, const unsigned int* d_n_leave, const unsigned int* d_rank_count,
+                                                               unsigned int capacity)
+    {
+    __shared__ unsigned int s_off[66];
+    if (threadIdx.x == 0)
+        {
+        unsigned int run = 0, most = 0;
+        for (unsigned int r = 0; r < a.n_ranks; r++)
+            {
+            s_off[r] = run;
+            const unsigned int c = d_rank_count[r];
+            run += c;
+            most = max(most, c);
+            }
+        s_off[a.n_ranks] = run;
+        // more leavers than the key array holds: the list is incomplete, which every receiver learns from a count no
+        // message can have (all ranks then start over, this one with a larger array)
+        s_off[65] = *d_n_leave > capacity ? 0xffffffffu : most;
+        }
+    __syncthreads();
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < a.n_ranks)
+        {
+        long long* h = a.d_out + (size_t)k * (a.slot_rows + 1) * HMD_MIGRATE_ROW_WORDS;
+        h[0] = (long long)(s_off[k + 1] - s_off[k]);
+        h[1] = (long long)s_off[65];
+        h[2] = (long long)a.slot_rows;
+        }
+    const unsigned int n = min(*d_n_leave, capacity);
+    if (k >= n)
+        return;
+    const unsigned long long key = a.d_keys[k];
+    const unsigned int i = (unsigned int)(key & 0xffffffffull);
+    const unsigned int dest = (unsigned int)(key >> 32);
+    if (dest >= a.n_ranks)
+        return; // (an unused place of the key array: only when more particles leave than it holds, and then the host starts over)
+    const unsigned int local = k - s_off[dest];
+    if (local >= a.slot_rows)
+        return; // does not fit this round's messages
+    const size_t out_row = (size_t)dest * (a.slot_rows + 1) + 1 + local;
+    const double4 p = hmd_ld4(a.arrays.d_pos + i);
+    const double4 v = hmd_ld4(a.arrays.d_vel + i);
+    const hmd_scalar3 acc = a.arrays.d_accel[i];
+    const hmd_int3 img = a.arrays.d_image[i];
+    double x[3] = {p.x, p.y, p.z};
+    long long im[3] = {img.x, img.y, img.z};
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+        {
+        const double f = HMD_SUB(x[d], a.global_lo[d]) / a.global_L[d];
+        const double w = a.decomposed[d] ? floor(f) : 0.0;
+        x[d] = HMD_SUB(x[d], HMD_MUL(w, a.global_L[d]));
+        im[d] += (long long)w;
+        }
+    long long* row = a.d_out + out_row * HMD_MIGRATE_ROW_WORDS;
+    row[0] = bits_of(x[0]);
+    row[1] = bits_of(x[1]);
+    row[2] = bits_of(x[2]);
+    row[3] = bits_of(p.w);
+    row[4] = bits_of(v.x);
+    row[5] = bits_of(v.y);
+    row[6] = bits_of(v.z);
+    row[7] = bits_of(v.w);
+    row[8] = bits_of(acc.x);
+    row[9] = bits_of(acc.y);
+    row[10] = bits_of(acc.z);
+    row[11] = im[0];
+    row[12] = im[1];
+    row[13] = im[2];
+    row[14] = (long long)(int)a.arrays.d_tag[i];
+    row[15] = (long long)(int)a.arrays.d_body[i];
+    row[16] = bits_of(a.arrays.d_charge[i]);
+    row[17] = bits_of(a.arrays.d_diameter[i]);
+    }
+
+// (the word also goes, stamped, to mapped pinned memory the host polls, when the caller names it: hmd_publish_words
+// without a launch of its own)
+__device__ __forceinline__ void comm_word_out(unsigned int* d_words, unsigned long long* d_published, unsigned int stamp, unsigned int i, unsigned int v)
+    {
+    d_words[i] = v;
+    if (d_published)
+        __hip_atomic_store(d_published + i, ((unsigned long long)stamp << 32) | (unsigned long long)v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+__global__ void __launch_bounds__(64) migrate_headers_and_kernel(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, const unsigned int* d_extra,
+                                                                 unsigned int n_extra, unsigned int* d_words, unsigned long long* d_published, unsigned int stamp)
+    {
+    const unsigned int r = threadIdx.x;
+    if (r < n_ranks)
+        {
+        const long long* h = d_in + (size_t)r * (slot_rows + 1) * HMD_MIGRATE_ROW_WORDS;
+        comm_word_out(d_words, d_published, stamp, 2 * r, (unsigned int)h[0]);
+        comm_word_out(d_words, d_published, stamp, 2 * r + 1, (unsigned int)h[1]);
+        }
+    if (r < n_extra)
+        comm_word_out(d_words, d_published, stamp, 2 * n_ranks + r, d_extra[r]);
+    }
+
+__global__ void __launch_bounds__(256) pack_init_slots_dev_kernel(hmd_pack_pos_args_t a, const unsigned int* d_tag, hmd_ghost_slots_t s, const unsigned int* d_total,
+                                                                  const unsigned int* d_dir_count, const unsigned int* d_dir_dest, unsigned int n_dir,
+                                                                  unsigned int capacity, const unsigned long long* d_sorted_keys, unsigned int* d_send_idx_out,
+                                                                  unsigned char* d_send_dir_out)
+    {
+    // rows per destination rank from the rows per direction (the send list is sorted by direction, and the directions
+    // by destination rank), their prefix sums, and whether any message is too small for its rows
+    __shared__ unsigned int s_off[HMD_GHOST_SLOTS_MAX_RANKS + 2];
+    if (threadIdx.x == 0)
+        {
+        unsigned int rows[HMD_GHOST_SLOTS_MAX_RANKS];
+        for (unsigned int r = 0; r < s.n_ranks; r++)
+            rows[r] = 0;
+        for (unsigned int k = 0; k < n_dir; k++)
+            rows[d_dir_dest[k]] += d_dir_count[k];
+        unsigned int run = 0, flag = 0;
+        for (unsigned int r = 0; r < s.n_ranks; r++)
+            {
+            s_off[r] = run;
+            run += rows[r];
+            if (rows[r] > s.cap[r])
+                flag = 1;
+            }
+        s_off[s.n_ranks] = run;
+        // bit 1: the send list outgrew its key array and is incomplete (all ranks start over, this one with a larger array)
+        if (*d_total > capacity)
+            flag |= 2u;
+        s_off[HMD_GHOST_SLOTS_MAX_RANKS + 1] = flag;
+        }
+    __syncthreads();
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < s.n_ranks)
+        hmd_st4(a.d_out + s.row0[k], hmd_uint_as_double(s_off[k + 1] - s_off[k]), hmd_uint_as_double(s_off[HMD_GHOST_SLOTS_MAX_RANKS + 1]), 0.0, 0.0);
+    const unsigned int n_send = min(*d_total, capacity);
+    if (k >= n_send)
+        return;
+    // the send list either exists (d_send_idx, d_send_shift_id) or is taken from the sorted keys here and stored for the
+    // exchanges of the steps to come (hmd_ghost_split_keys without a launch of its own)
+    unsigned int i, dir;
+    if (d_sorted_keys)
+        {
+        const unsigned long long key = d_sorted_keys[k];
+        i = (unsigned int)(key & 0xffffffffull);
+        dir = (unsigned int)(key >> 32) & 0xffu;
+        d_send_idx_out[k] = i;
+        d_send_dir_out[k] = (unsigned char)dir;
+        }
+    else
+        {
+        i = a.d_send_idx[k];
+        dir = a.d_send_shift_id[k];
+        }
+    unsigned int r = 0;
+    while (r + 1 < s.n_ranks && s_off[r + 1] <= k)
+        r++;
+    const unsigned int local = k - s_off[r];
+    if (local >= s.cap[r])
+        return;
+    const double4 p = hmd_ld4(a.d_pos + i);
+    const hmd_scalar3 sh = a.d_shift_table[dir];
+    const double w = __hiloint2double((int)d_tag[i], (int)hmd_double_as_uint(p.w));
+    hmd_st4(a.d_out + (size_t)s.row0[r] + 1 + local, HMD_ADD(p.x, sh.x), HMD_ADD(p.y, sh.y), HMD_ADD(p.z, sh.z), w);
+    }
+
+__global__ void __launch_bounds__(64) slot_headers_and_kernel(const hmd_scalar4* d_in, hmd_ghost_slots_t s, const unsigned int* d_extra, unsigned int n_extra,
+                                                              unsigned int* d_words, unsigned long long* d_published, unsigned int stamp)
+    {
+    const unsigned int r = threadIdx.x;
+    if (r < s.n_ranks)
+        {
+        const double4 p = hmd_ld4(d_in + s.row0[r]);
+        comm_word_out(d_words, d_published, stamp, 2 * r, hmd_double_as_uint(p.x));
+        comm_word_out(d_words, d_published, stamp, 2 * r + 1, hmd_double_as_uint(p.y));
+        }
+    if (r < n_extra)
+        comm_word_out(d_words, d_published, stamp, 2 * s.n_ranks + r, d_extra[r]);
+    }
+
+// zeroes a few counters and fills a key array with the padding that sorts behind every key: one launch for the two
+// memsets that precede a counting kernel
+__global__ void __launch_bounds__(256) comm_prep_kernel(unsigned int* d_counters, unsigned int n_counters, unsigned long long* d_keys, unsigned int n_keys)
+    {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_counters)
+        d_counters[k] = 0u;
+    if (k < n_keys)
+        d_keys[k] = ~0ull;
+    }
+
 __global__ void __launch_bounds__(256) pack_pos_kernel(hmd_pack_pos_args_t a)
     {
     const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -713,6 +905,72 @@ extern "C" int hmd_unpack_ghost_init_slots(const hmd_unpack_ghost_init_args_t* a
     HMD_REQUIRE(args->d_in && p.d_pos && p.d_image && p.d_tag && p.d_body && p.d_charge && p.d_diameter, HMD_ERR_INVALID_ARGUMENT,
                 "hmd_unpack_ghost_init_slots: d_in and the pos, image, tag, body, charge and diameter arrays are required");
     hipLaunchKernelGGL(unpack_init_slots_kernel, dim3(hmd_div_up(args->n, 256)), dim3(256), 0, (hipStream_t)stream, *args, *slots);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_migrate_pack_slots_dev(const hmd_migrate_pack_args_t* args, const unsigned int* d_n_leave, const unsigned int* d_rank_count,
+                                          unsigned int capacity, void* stream)
+    {
+    HMD_REQUIRE(args && d_n_leave && d_rank_count, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack_slots_dev: args, d_n_leave and d_rank_count are required");
+    HMD_REQUIRE(args->slot_rows >= 1 && args->n_ranks >= 1 && args->n_ranks <= 64 && args->d_out, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_pack_slots_dev: fixed-size messages (slot_rows >= 1) for 1 to 64 ranks and d_out are required");
+    HMD_REQUIRE(capacity == 0 || (pdata_arrays_complete(args->arrays) && args->d_keys), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_pack_slots_dev: all particle arrays and d_keys are required");
+    for (int d = 0; d < 3; d++)
+        HMD_REQUIRE(args->global_L[d] > 0.0, HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_pack_slots_dev: empty box");
+    hipLaunchKernelGGL(migrate_pack_dev_kernel, dim3(hmd_div_up(std::max(capacity, args->n_ranks), 256)), dim3(256), 0, (hipStream_t)stream, *args, d_n_leave,
+                       d_rank_count, capacity);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_comm_prep(unsigned int* d_counters, unsigned int n_counters, unsigned long long* d_keys, unsigned int n_keys, void* stream)
+    {
+    HMD_REQUIRE((n_counters == 0 || d_counters) && (n_keys == 0 || d_keys), HMD_ERR_INVALID_ARGUMENT, "hmd_comm_prep: an array is NULL");
+    const unsigned int n = std::max(n_counters, n_keys);
+    if (n == 0)
+        return HMD_OK;
+    hipLaunchKernelGGL(comm_prep_kernel, dim3(hmd_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, d_counters, n_counters, d_keys, n_keys);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_migrate_slot_headers_and(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, const unsigned int* d_extra,
+                                            unsigned int n_extra, unsigned int* d_words, unsigned long long* d_published, unsigned int stamp, void* stream)
+    {
+    HMD_REQUIRE(d_in && d_words && slot_rows >= 1 && n_ranks >= 1 && n_ranks <= 64, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_migrate_slot_headers_and: d_in, d_words, slot_rows >= 1 and 1 to 64 ranks are required");
+    HMD_REQUIRE(n_extra <= 64 && (n_extra == 0 || d_extra), HMD_ERR_INVALID_ARGUMENT, "hmd_migrate_slot_headers_and: at most 64 extra words");
+    hipLaunchKernelGGL(migrate_headers_and_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, slot_rows, n_ranks, d_extra, n_extra, d_words, d_published,
+                       stamp);
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_pack_ghost_init_slots_dev(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, const hmd_ghost_slots_t* slots,
+                                             const unsigned int* d_total, const unsigned int* d_dir_count, const unsigned int* d_dir_dest, unsigned int n_dir,
+                                             unsigned int capacity, const unsigned long long* d_sorted_keys, void* stream)
+    {
+    HMD_REQUIRE(args && slots && d_total, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots_dev: args, slots and d_total are required");
+    HMD_REQUIRE(slots->n_ranks >= 1 && slots->n_ranks <= HMD_GHOST_SLOTS_MAX_RANKS, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots_dev: 1 to 64 ranks");
+    for (unsigned int r = 0; r + 1 < slots->n_ranks; r++)
+        HMD_REQUIRE(slots->row0[r] + slots->cap[r] + 1 <= slots->row0[r + 1], HMD_ERR_INVALID_ARGUMENT,
+                    "hmd_pack_ghost_init_slots_dev: messages must not overlap in the buffer");
+    HMD_REQUIRE(n_dir <= 26 && (n_dir == 0 || (d_dir_count && d_dir_dest)), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_init_slots_dev: at most 26 directions, with their counts and destination ranks");
+    HMD_REQUIRE(args->d_out, HMD_ERR_INVALID_ARGUMENT, "hmd_pack_ghost_init_slots_dev: d_out is required");
+    HMD_REQUIRE(capacity == 0 || (args->d_pos && args->d_send_idx && args->d_send_shift_id && args->d_shift_table && d_tag), HMD_ERR_INVALID_ARGUMENT,
+                "hmd_pack_ghost_init_slots_dev: all array arguments are required");
+    hipLaunchKernelGGL(pack_init_slots_dev_kernel, dim3(hmd_div_up(std::max(capacity, slots->n_ranks), 256)), dim3(256), 0, (hipStream_t)stream, *args, d_tag,
+                       *slots, d_total, d_dir_count, d_dir_dest, n_dir, capacity, d_sorted_keys, const_cast<unsigned int*>(args->d_send_idx),
+                       const_cast<unsigned char*>(args->d_send_shift_id));
+    return hmd_launch_status();
+    }
+
+extern "C" int hmd_ghost_slot_headers_and(const hmd_scalar4* d_in, const hmd_ghost_slots_t* slots, const unsigned int* d_extra, unsigned int n_extra,
+                                          unsigned int* d_words, unsigned long long* d_published, unsigned int stamp, void* stream)
+    {
+    HMD_REQUIRE(d_in && d_words && slots && slots->n_ranks >= 1 && slots->n_ranks <= HMD_GHOST_SLOTS_MAX_RANKS, HMD_ERR_INVALID_ARGUMENT,
+                "hmd_ghost_slot_headers_and: d_in, d_words and 1 to 64 ranks are required");
+    HMD_REQUIRE(n_extra <= 64 && (n_extra == 0 || d_extra), HMD_ERR_INVALID_ARGUMENT, "hmd_ghost_slot_headers_and: at most 64 extra words");
+    hipLaunchKernelGGL(slot_headers_and_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, *slots, d_extra, n_extra, d_words, d_published, stamp);
     return hmd_launch_status();
     }
 

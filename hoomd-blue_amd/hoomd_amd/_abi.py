@@ -297,6 +297,11 @@ _SIGNATURES = {
     "hmd_ghost_slot_headers": (C.c_int, [vp, C.POINTER(GhostSlots), vp, vp]),
     "hmd_unpack_ghost_init_slots": (C.c_int, [C.POINTER(UnpackGhostInitArgs), C.POINTER(GhostSlots), vp]),
     "hmd_migrate_slot_headers": (C.c_int, [vp, u32, u32, vp, vp]),
+    "hmd_migrate_pack_slots_dev": (C.c_int, [C.POINTER(MigratePackArgs), vp, vp, u32, vp]),
+    "hmd_migrate_slot_headers_and": (C.c_int, [vp, u32, u32, vp, u32, vp, vp, u32, vp]),
+    "hmd_pack_ghost_init_slots_dev": (C.c_int, [C.POINTER(PackPosArgs), vp, C.POINTER(GhostSlots), vp, vp, vp, u32, u32, vp, vp]),
+    "hmd_ghost_slot_headers_and": (C.c_int, [vp, C.POINTER(GhostSlots), vp, u32, vp, vp, u32, vp]),
+    "hmd_comm_prep": (C.c_int, [vp, u32, vp, u32, vp]),
     "hmd_vote_plan": (C.c_int, [C.POINTER(VotePlanArgs), vp]),
     "hmd_migrate_pack": (C.c_int, [C.POINTER(MigratePackArgs), vp]),
     "hmd_migrate_fill": (C.c_int, [C.POINTER(MigrateFillArgs), vp]),

@@ -570,6 +570,7 @@ class Communicator:
         self.cpp.setFixedMigrate(os.environ.get("HOOMD_AMD_FIXED_MIGRATE", "1") != "0")
         self.cpp.setMigrateSlotRows(int(os.environ.get("HOOMD_AMD_MIGRATE_SLOT_ROWS", "1024")))
         self.cpp.setUseGhostSlots(os.environ.get("HOOMD_AMD_GHOST_SLOTS", "1") != "0")
+        self.cpp.setUseDeviceCounts(os.environ.get("HOOMD_AMD_DEVICE_COUNTS", "1") != "0")
         if "HOOMD_AMD_GHOST_SLOT_ROOM" in os.environ:  # "div,pad" (experiments, tests of the too-small case)
             div, pad = (int(v) for v in os.environ["HOOMD_AMD_GHOST_SLOT_ROOM"].split(","))
             self.cpp.setGhostSlotRoom(div, pad)
@@ -620,6 +621,7 @@ class Communicator:
     n_migrated_in = property(lambda self: self.cpp.n_migrated_in)
     n_vote_exchanges = property(lambda self: self.cpp.n_vote_exchanges)
     n_count_exchanges = property(lambda self: self.cpp.n_count_exchanges)
+    n_device_count_exchanges = property(lambda self: self.cpp.n_device_count_exchanges)
     n_ghost_slot_overflows = property(lambda self: self.cpp.n_ghost_slot_overflows)
     fixed_migrate = property(lambda self: self.cpp.fixed_migrate)
     migrate_slot_rows = property(lambda self: self.cpp.migrate_slot_rows)

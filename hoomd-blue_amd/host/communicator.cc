@@ -106,6 +106,8 @@ CommunicatorGPU::CommunicatorGPU(std::shared_ptr<SystemDefinition> sysdef, std::
     m_shift_table.resize(std::max<size_t>(shifts.size(), 1), false);
     m_dir_mask.upload(masks.data(), masks.size());
     m_shift_table.upload(shifts.data(), shifts.size());
+    m_dir_dest_dev.resize(std::max<size_t>(m_dir_dest.size(), 1), false);
+    m_dir_dest_dev.upload(m_dir_dest.data(), m_dir_dest.size());
 
     // is every other rank a halo partner?
     std::vector<unsigned int> peers(m_dir_dest);
@@ -199,9 +201,145 @@ void CommunicatorGPU::communicate(uint64_t timestep)
     }
 
 // ---- migration ----------------------------------------------------------------------------------
+// Migration with fixed-size messages and every size read on the device: owner decision, sort of the (padded) key array,
+// pack, exchange, and only then one look of the host at the counts that stayed and the headers that arrived.
+bool CommunicatorGPU::migrateParticlesDeviceCounts()
+    {
+    const unsigned int N = m_pdata->getN();
+    m_pdata->setNGhosts(0);
+    ensure(m_mig_dest, std::max(N, 1u), 1.125);
+    hmd_migrate_dest_args_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.d_pos = m_pdata->pos();
+    a.N = N;
+    a.rank = m_rank;
+    for (int d = 0; d < 3; d++)
+        {
+        a.global_lo[d] = m_glo[d];
+        a.global_L[d] = m_gL[d];
+        a.grid[d] = m_grid[d];
+        a.decomposed[d] = m_decomposed[d] ? 1 : 0;
+        }
+    a.d_dest = m_mig_dest.get();
+    a.d_n_leave = m_mig_counters.get();
+    a.d_rank_count = m_mig_counters.get() + 1;
+    a.n_ranks = m_world;
+    hmd_migrate_pack_args_t pk;
+    std::memset(&pk, 0, sizeof(pk));
+    for (int d = 0; d < 3; d++)
+        {
+        pk.global_lo[d] = m_glo[d];
+        pk.global_L[d] = m_gL[d];
+        pk.decomposed[d] = m_decomposed[d] ? 1 : 0;
+        }
+    pk.n_ranks = m_world;
+    const unsigned int n_words = 3 * m_world + 1;
+    ensure(m_count_in, n_words, 1.0, 0);
+    std::vector<unsigned int> words(n_words);
+    unsigned int slot_rows = 0, n_leave = 0;
+    while (true)
+        {
+        const unsigned int cap = (unsigned int)m_mig_keys.size();
+        // (counters to zero; places past the last key hold a destination no rank has, so they sort behind every key)
+        abiCheck(hmd_comm_prep(m_mig_counters.get(), 1 + m_world, m_mig_keys.get(), cap, nullptr), "hmd_comm_prep");
+        a.d_keys = m_mig_keys.get();
+        a.capacity = cap;
+        abiCheck(hmd_migrate_dest(&a, nullptr), "hmd_migrate_dest");
+        sortKeys(m_mig_keys, cap, 32 + bitsFor(m_world));
+        pk.arrays = pdataArrays();
+        pk.d_keys = m_keys_sorted.get();
+        bool keys_overflowed = false;
+        while (true)
+            {
+            slot_rows = m_mig_slot_rows;
+            const size_t rows = (size_t)m_world * (slot_rows + 1);
+            if (m_mig_out.size() < rows * ROW_WORDS)
+                m_mig_out.resize(rows * ROW_WORDS, false);
+            if (m_mig_in.size() < rows * ROW_WORDS)
+                m_mig_in.resize(rows * ROW_WORDS, false);
+            pk.slot_rows = slot_rows;
+            pk.d_out = m_mig_out.get();
+            abiCheck(hmd_migrate_pack_slots_dev(&pk, m_mig_counters.get(), m_mig_counters.get() + 1, cap, nullptr), "hmd_migrate_pack_slots_dev");
+            const std::vector<unsigned int> each(m_world, slot_rows + 1);
+            m_transport->allToAll((uintptr_t)m_mig_out.get(), each, (uintptr_t)m_mig_in.get(), each, ROW_BYTES, 0);
+            unsigned int stamp = 0;
+            unsigned long long* d_pub = m_readback.expect(n_words, stamp);
+            abiCheck(hmd_migrate_slot_headers_and(m_mig_in.get(), slot_rows, m_world, m_mig_counters.get(), 1 + m_world, m_count_in.get(), d_pub, stamp, nullptr),
+                     "hmd_migrate_slot_headers_and");
+            m_readback.finish(words.data(), "migration headers and counts");
+            n_device_count_exchanges++;
+            unsigned int most = 0;
+            for (unsigned int r = 0; r < m_world; r++)
+                {
+                if (words[2 * r + 1] == 0xffffffffu)
+                    keys_overflowed = true; // some rank's list of leavers was incomplete: every rank sees it and starts over
+                else
+                    most = std::max(most, words[2 * r + 1]);
+                }
+            if (keys_overflowed || most <= slot_rows)
+                break;
+            m_mig_slot_rows = 2 * most; // the same decision on every rank: send again with room for all
+            }
+        n_leave = words[2 * m_world];
+        if (!keys_overflowed)
+            break;
+        if (n_leave > cap)
+            m_mig_keys.resize((size_t)(n_leave * 1.25) + 1024, false);
+        }
+    std::vector<unsigned int> recv_counts(m_world, 0);
+    unsigned int n_recv = 0;
+    for (unsigned int r = 0; r < m_world; r++)
+        {
+        recv_counts[r] = words[2 * r];
+        n_recv += recv_counts[r];
+        }
+    n_migrated_out += n_leave;
+    n_migrated_in += n_recv;
+    if (n_leave == 0 && n_recv == 0)
+        return false;
+    const unsigned int n_keep = N - n_leave;
+    if (n_leave)
+        {
+        ensure(m_scratch, 2 * (size_t)n_leave);
+        hmd_migrate_fill_args_t f;
+        std::memset(&f, 0, sizeof(f));
+        f.arrays = pdataArrays();
+        f.d_dest = m_mig_dest.get();
+        f.rank = m_rank;
+        f.N = N;
+        f.d_keys = m_keys_sorted.get();
+        f.n_leave = n_leave;
+        f.d_scratch = m_scratch.get();
+        abiCheck(hmd_migrate_fill(&f, nullptr), "hmd_migrate_fill");
+        }
+    m_pdata->resizeOwned(n_keep + n_recv);
+    if (n_recv)
+        {
+        hmd_migrate_unpack_args_t u;
+        std::memset(&u, 0, sizeof(u));
+        u.arrays = pdataArrays();
+        u.d_in = m_mig_in.get();
+        u.first = n_keep;
+        u.n = n_recv;
+        u.slot_rows = slot_rows;
+        u.n_ranks = m_world;
+        unsigned int off = 0;
+        for (unsigned int r = 0; r < m_world; r++)
+            {
+            u.recv_off[r] = off;
+            off += recv_counts[r];
+            }
+        u.recv_off[m_world] = off;
+        abiCheck(hmd_migrate_unpack(&u, nullptr), "hmd_migrate_unpack");
+        }
+    return true;
+    }
+
 bool CommunicatorGPU::migrateParticles()
     {
     ScopedKernelTimer timer("comm_migrate");
+    if (m_fixed_migrate && m_device_counts && 3 * m_world + 1 <= 64)
+        return migrateParticlesDeviceCounts();
     const unsigned int N = m_pdata->getN();
     m_pdata->setNGhosts(0); // ghosts are exchanged again afterwards
     ensure(m_mig_dest, std::max(N, 1u), 1.125);
@@ -361,6 +499,105 @@ bool CommunicatorGPU::migrateParticles()
     return true;
     }
 
+// The ghost layer with messages sized from the previous exchange and every size read on the device: send list, sort of
+// the (padded) key array, pack, exchange, then one look of the host at the counts that stayed and the headers that
+// arrived.  True when the ghosts are in place; false when a message was too small (the caller then exchanges counts
+// first, with the send list this call leaves behind).
+bool CommunicatorGPU::exchangeGhostsDeviceCounts(Scalar r_ghost, hmd_ghost_send_list_args_t& a, hmd_pack_pos_args_t& pa, hmd_unpack_ghost_init_args_t& u,
+                                                 unsigned int& total)
+    {
+    const unsigned int ndir = (unsigned int)m_dir_dest.size();
+    auto room = [this](unsigned int rows) { return rows + (m_ghost_room_div ? rows / m_ghost_room_div : 0u) + m_ghost_room_pad; };
+    // the key array is sorted whole: keep it close to what the previous exchange needed
+    unsigned int prev_total = 0;
+    for (unsigned int r = 0; r < m_world; r++)
+        prev_total += m_prev_send_rows[r];
+    m_ghost_key_cap = std::max(m_ghost_key_cap, prev_total + prev_total / 8 + 1024);
+    const unsigned int n_words = 2 * m_world + 1 + ndir;
+    ensure(m_count_in, n_words, 1.0, 0);
+    std::vector<unsigned int> words(n_words);
+    hmd_ghost_slots_t so, si;
+    while (true)
+        {
+        const unsigned int cap = m_ghost_key_cap;
+        ensure(m_keys, cap, 1.0, 0);
+        abiCheck(hmd_comm_prep(m_send_counters.get(), 1 + 26, m_keys.get(), cap, nullptr), "hmd_comm_prep");
+        a.d_keys = m_keys.get();
+        a.capacity = cap;
+        abiCheck(hmd_ghost_send_list(&a, nullptr), "hmd_ghost_send_list");
+        sortKeys(m_keys, cap, 32 + 5);
+        ensure(m_send_idx, cap, 1.0, 0);
+        ensure(m_send_dir, cap, 1.0, 0);
+        std::memset(&so, 0, sizeof(so));
+        std::memset(&si, 0, sizeof(si));
+        so.n_ranks = si.n_ranks = m_world;
+        std::vector<unsigned int> out_rows(m_world), in_rows(m_world);
+        unsigned int out_total = 0, in_total = 0;
+        for (unsigned int r = 0; r < m_world; r++)
+            {
+            so.cap[r] = room(m_prev_send_rows[r]);
+            si.cap[r] = room(m_prev_recv_rows[r]);
+            so.row0[r] = out_total;
+            si.row0[r] = in_total;
+            out_rows[r] = so.cap[r] + 1;
+            in_rows[r] = si.cap[r] + 1;
+            out_total += out_rows[r];
+            in_total += in_rows[r];
+            }
+        ensure(m_init_out, out_total);
+        ensure(m_init_in, in_total);
+        pa.d_out = m_init_out.get();
+        pa.d_pos = m_pdata->pos();
+        pa.d_send_idx = m_send_idx.get();
+        pa.d_send_shift_id = m_send_dir.get();
+        pa.d_shift_table = m_shift_table.get();
+        // (the send list -- particle index and direction of every row -- is split off the sorted keys by the pack itself)
+        abiCheck(hmd_pack_ghost_init_slots_dev(&pa, m_pdata->tag(), &so, m_send_counters.get(), m_send_counters.get() + 1, m_dir_dest_dev.get(), ndir, cap,
+                                               m_keys_sorted.get(), nullptr),
+                 "hmd_pack_ghost_init_slots_dev");
+        m_transport->allToAll((uintptr_t)m_init_out.get(), out_rows, (uintptr_t)m_init_in.get(), in_rows, sizeof(Scalar4), 0);
+        unsigned int stamp = 0;
+        unsigned long long* d_pub = m_readback.expect(n_words, stamp);
+        abiCheck(hmd_ghost_slot_headers_and(m_init_in.get(), &si, m_send_counters.get(), 1 + ndir, m_count_in.get(), d_pub, stamp, nullptr),
+                 "hmd_ghost_slot_headers_and");
+        m_readback.finish(words.data(), "ghost message headers and counts");
+        n_device_count_exchanges++;
+        total = words[2 * m_world];
+        bool list_overflowed = false;
+        for (unsigned int r = 0; r < m_world; r++)
+            list_overflowed = list_overflowed || (words[2 * r + 1] & 2u) != 0;
+        if (!list_overflowed)
+            break;
+        // some rank's send list was incomplete: every rank sees it and starts over, that rank with a larger array
+        if (total > cap)
+            m_ghost_key_cap = (unsigned int)(total * 1.25) + 1024;
+        }
+    m_n_send = total;
+    std::fill(m_send_rows.begin(), m_send_rows.end(), 0u);
+    for (unsigned int k = 0; k < ndir; k++)
+        m_send_rows[m_dir_dest[k]] += words[2 * m_world + 1 + k];
+    bool too_small = false;
+    for (unsigned int r = 0; r < m_world; r++)
+        too_small = too_small || (words[2 * r + 1] & 1u) != 0;
+    if (too_small)
+        {
+        n_ghost_slot_overflows++; // every rank falls back to the exchange with counts
+        return false;
+        }
+    for (unsigned int r = 0; r < m_world; r++)
+        {
+        m_recv_rows[r] = words[2 * r];
+        si.off[r + 1] = si.off[r] + m_recv_rows[r];
+        }
+    const unsigned int n_ghost = si.off[m_world];
+    m_pdata->setNGhosts(n_ghost);
+    u.d_in = m_init_in.get();
+    u.n = n_ghost;
+    u.arrays = pdataArrays();
+    abiCheck(hmd_unpack_ghost_init_slots(&u, &si, nullptr), "hmd_unpack_ghost_init_slots");
+    return true;
+    }
+
 // ---- ghost layer ----------------------------------------------------------------------------------
 void CommunicatorGPU::exchangeGhosts(Scalar r_ghost)
     {
@@ -384,6 +621,7 @@ void CommunicatorGPU::exchangeGhosts(Scalar r_ghost)
         m_keys.resize(std::max<size_t>(N / 2, 1024), false);
     // plan, per-direction selection and counts in one kernel; one readback; one sort puts the keys
     // (direction, particle index) in the order of the send list
+    const bool device_counts = m_device_counts && m_use_ghost_slots && m_all_peers && m_have_prev_rows && 2 * m_world + 27 <= 64;
     hmd_ghost_send_list_args_t a;
     std::memset(&a, 0, sizeof(a));
     a.ghost_plan.d_pos = m_pdata->pos();
@@ -396,43 +634,49 @@ void CommunicatorGPU::exchangeGhosts(Scalar r_ghost)
             a.ghost_plan.mask |= 3u << (2 * d);
     a.d_dir_mask = m_dir_mask.get();
     a.n_dir = ndir;
-    unsigned int counters[27];
-    while (true)
-        {
-        m_send_counters.zero();
-        a.d_keys = m_keys.get();
-        a.capacity = (unsigned int)m_keys.size();
-        a.d_total = m_send_counters.get();
-        a.d_dir_count = m_send_counters.get() + 1;
-        abiCheck(hmd_ghost_send_list(&a, nullptr), "hmd_ghost_send_list");
-        m_readback.read(m_send_counters.get(), 1 + ndir, counters, "ghost send counts");
-        if (counters[0] <= m_keys.size())
-            break;
-        m_keys.resize((size_t)(counters[0] * 1.25) + 1024, false);
-        }
-    const unsigned int total = counters[0];
-    sortKeys(m_keys, total, 32 + 5);
-    ensure(m_send_idx, total, 1.25, 1024);
-    ensure(m_send_dir, total, 1.25, 1024);
-    abiCheck(hmd_ghost_split_keys(m_keys_sorted.get(), total, m_send_idx.get(), m_send_dir.get(), nullptr), "hmd_ghost_split_keys");
-    m_n_send = total;
-    std::fill(m_send_rows.begin(), m_send_rows.end(), 0u);
-    for (unsigned int k = 0; k < ndir; k++)
-        m_send_rows[m_dir_dest[k]] += counters[1 + k];
-    // one message per peer carries position, type and tag; the unpack kernel also sets the fields that are not
-    // communicated
+    a.d_total = m_send_counters.get();
+    a.d_dir_count = m_send_counters.get() + 1;
     hmd_pack_pos_args_t pa;
     std::memset(&pa, 0, sizeof(pa));
+    hmd_unpack_ghost_init_args_t u;
+    std::memset(&u, 0, sizeof(u));
+    u.first = N;
+    unsigned int total = 0;
+    bool done = false;
+    if (device_counts)
+        done = exchangeGhostsDeviceCounts(r_ghost, a, pa, u, total);
+    else
+        {
+        unsigned int counters[27];
+        while (true)
+            {
+            m_send_counters.zero();
+            a.d_keys = m_keys.get();
+            a.capacity = (unsigned int)m_keys.size();
+            abiCheck(hmd_ghost_send_list(&a, nullptr), "hmd_ghost_send_list");
+            m_readback.read(m_send_counters.get(), 1 + ndir, counters, "ghost send counts");
+            if (counters[0] <= m_keys.size())
+                break;
+            m_keys.resize((size_t)(counters[0] * 1.25) + 1024, false);
+            }
+        total = counters[0];
+        sortKeys(m_keys, total, 32 + 5);
+        ensure(m_send_idx, total, 1.25, 1024);
+        ensure(m_send_dir, total, 1.25, 1024);
+        abiCheck(hmd_ghost_split_keys(m_keys_sorted.get(), total, m_send_idx.get(), m_send_dir.get(), nullptr), "hmd_ghost_split_keys");
+        m_n_send = total;
+        std::fill(m_send_rows.begin(), m_send_rows.end(), 0u);
+        for (unsigned int k = 0; k < ndir; k++)
+            m_send_rows[m_dir_dest[k]] += counters[1 + k];
+        }
+    // one message per peer carries position, type and tag; the unpack kernel also sets the fields that are not
+    // communicated
     pa.d_pos = m_pdata->pos();
     pa.d_send_idx = m_send_idx.get();
     pa.d_send_shift_id = m_send_dir.get();
     pa.d_shift_table = m_shift_table.get();
     pa.n_send = total;
-    hmd_unpack_ghost_init_args_t u;
-    std::memset(&u, 0, sizeof(u));
-    u.first = N;
-    bool done = false;
-    if (m_use_ghost_slots && m_all_peers && m_have_prev_rows && 2 * m_world <= 64)
+    if (!done && !device_counts && m_use_ghost_slots && m_all_peers && m_have_prev_rows && 2 * m_world <= 64)
         {
         // Messages with room for somewhat more rows than the same pair of ranks exchanged last time -- a number both
         // ends know -- each headed by its row count and by whether any message of its sender was too small.  Every

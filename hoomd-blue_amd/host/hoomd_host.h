@@ -161,6 +161,9 @@ class WordReadback
     //! for it -- in between the caller queues more work, so the device does not sit idle while the host looks
     void begin(const unsigned int* d_words, unsigned int n);
     void finish(unsigned int* out, const char* what);
+    //! for a kernel that publishes n words itself (stamped, as hmd_publish_words does): where to, and the stamp to use;
+    //! finish() then waits for them
+    unsigned long long* expect(unsigned int n, unsigned int& stamp);
 
     private:
     PinnedWords m_pinned; // 64 slots of 8 bytes
@@ -1248,6 +1251,7 @@ class NeighborListGPUBinned : public Compute
     uint64_t m_last_build_tstep = ~0ull;
 
     std::vector<unsigned int> m_Nmax;
+    unsigned int m_head_uniform_n = 0, m_head_uniform_nmax = 0; // places of the head list that hold i * Nmax, and that Nmax
     DeviceArray<unsigned int> m_d_Nmax, m_conditions, m_n_neigh, m_nlist, m_flag;
     DeviceArray<size_t> m_head_list, m_req_size;
     DeviceArray<Scalar4> m_last_pos;
@@ -1982,6 +1986,14 @@ class CommunicatorGPU : public Communicator
         {
         m_mig_slot_rows = std::max(n, 1u);
         }
+    //! Pack kernels read their sizes where the counting kernels left them (device memory) and the host looks at counts
+    //! and headers together, once per half of the exchange (fixed-size messages only); off: every count is fetched
+    //! before the kernel that needs it is launched
+    void setUseDeviceCounts(bool b)
+        {
+        m_device_counts = b;
+        }
+    uint64_t n_device_count_exchanges = 0;
     // statistics
     uint64_t n_migrated_out = 0, n_migrated_in = 0, n_vote_exchanges = 0, n_count_exchanges = 0, n_ghost_slot_overflows = 0;
     bool usesFixedMigrate() const
@@ -1995,6 +2007,8 @@ class CommunicatorGPU : public Communicator
 
     private:
     hmd_pdata_arrays_t pdataArrays() const;
+    bool migrateParticlesDeviceCounts();
+    bool exchangeGhostsDeviceCounts(Scalar r_ghost, hmd_ghost_send_list_args_t& a, hmd_pack_pos_args_t& pa, hmd_unpack_ghost_init_args_t& u, unsigned int& total);
     void sortKeys(DeviceArray<unsigned long long>& keys, unsigned int n, unsigned int key_bits);
     void updateGhostsWithVote(unsigned int* d_flag, hipStream_t stream);
     void buildVotePlan();
@@ -2009,7 +2023,9 @@ class CommunicatorGPU : public Communicator
     std::array<double, 3> m_glo, m_gL;
     std::array<bool, 3> m_decomposed;
     bool m_force_migrate = true, m_in_communicate = false, m_ghosts_fresh = false, m_use_vote_rows = true;
-    bool m_all_peers = false, m_fixed_migrate = false, m_have_vote_plan = false;
+    bool m_all_peers = false, m_fixed_migrate = false, m_have_vote_plan = false, m_device_counts = true;
+    DeviceArray<unsigned int> m_dir_dest_dev;
+    unsigned int m_ghost_key_cap = 0;
     // one entry per direction towards a neighbor domain, sorted by destination rank
     std::vector<unsigned int> m_dir_dest;
     DeviceArray<unsigned int> m_dir_mask;

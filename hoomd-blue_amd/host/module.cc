@@ -236,6 +236,8 @@ PYBIND11_MODULE(_hoomd_amd, m)
         .def("setUseVoteRows", &CommunicatorGPU::setUseVoteRows)
         .def("setFixedMigrate", &CommunicatorGPU::setFixedMigrate)
         .def("setMigrateSlotRows", &CommunicatorGPU::setMigrateSlotRows)
+        .def("setUseDeviceCounts", &CommunicatorGPU::setUseDeviceCounts)
+        .def_readonly("n_device_count_exchanges", &CommunicatorGPU::n_device_count_exchanges)
         .def("setUseGhostSlots", &CommunicatorGPU::setUseGhostSlots)
         .def("forgetGhostRows", &CommunicatorGPU::forgetGhostRows)
         .def("setGhostSlotRoom", &CommunicatorGPU::setGhostSlotRoom)

@@ -72,6 +72,7 @@ void NeighborListGPUBinned::reallocatePerParticle()
     const size_t n = std::max(m_pdata->getMaxN(), 1u);
     m_n_neigh.resize(n, false);
     m_head_list.resize(n, false);
+    m_head_uniform_n = 0;
     m_last_pos.resize(n, false);
     m_n_ex_idx.resize(n, false);
     m_workspace.resize(hmd_nlist_head_list_workspace_bytes((unsigned int)n), false);
@@ -452,8 +453,17 @@ void NeighborListGPUBinned::buildHeadList()
     size_t req = 0;
     if (a.ntypes == 1)
         {
-        // uniform rows: the total is known without a readback
-        abiCheck(hmd_nlist_build_head_list(&a, nullptr), "hmd_nlist_build_head_list");
+        // uniform rows: head[i] = i * Nmax whoever particle i is, and the total is known without a readback.  The list
+        // is written for every place of the array at once and stays valid until the row length or the array changes
+        // (particles come and go on every rebuild of a decomposed run: no launch for that).
+        if (m_head_uniform_n < a.N || m_head_uniform_nmax != m_Nmax[0])
+            {
+            a.N = (unsigned int)std::min<size_t>(m_head_list.size(), 0xffffffffu);
+            abiCheck(hmd_nlist_build_head_list(&a, nullptr), "hmd_nlist_build_head_list");
+            m_head_uniform_n = a.N;
+            m_head_uniform_nmax = m_Nmax[0];
+            a.N = m_pdata->getN();
+            }
         req = (size_t)a.N * m_Nmax[0];
         }
     else

@@ -66,6 +66,15 @@ void WordReadback::begin(const unsigned int* d_words, unsigned int n)
     abiCheck(hmd_publish_words(d_words, n, reinterpret_cast<unsigned long long*>(m_pinned.deviceView()), m_stamp, nullptr), "hmd_publish_words");
     }
 
+unsigned long long* WordReadback::expect(unsigned int n, unsigned int& stamp)
+    {
+    if (n > 64)
+        throw std::runtime_error("WordReadback: more than 64 words");
+    m_n = n;
+    stamp = ++m_stamp;
+    return reinterpret_cast<unsigned long long*>(m_pinned.deviceView());
+    }
+
 void WordReadback::finish(unsigned int* out, const char* what)
     {
     volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(m_pinned.get());

@@ -739,6 +739,7 @@ int hmd_unpack_ghost_init_slots(const hmd_unpack_ghost_init_args_t* args, const 
    headers like its other counters instead of through a strided copy.  No counterpart in the reference. */
 int hmd_migrate_slot_headers(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, unsigned int* d_words, void* stream);
 
+
 /* Row maps for hmd_pack_ghost_positions_vote / hmd_unpack_ghost_positions from the message sizes: every
    message to or from another rank gets one extra row (the vote) after its data rows.  send_off / recv_off:
    exclusive prefix sums of the data rows per rank (n_ranks + 1 entries).  Outputs: d_out_row[send_off[n_ranks]],
@@ -812,6 +813,37 @@ typedef struct
     unsigned int send_off[65];
     } hmd_migrate_pack_args_t;
 int hmd_migrate_pack(const hmd_migrate_pack_args_t* args, void* stream);
+
+/* The packs of the fixed-size messages with their sizes read ON THE DEVICE, where the kernels before them left them, so
+   that the host does not fetch a count only to hand it back as an argument (the reference reads every count back and
+   sizes its sends from it: hoomd/CommunicatorGPU.cc:1924-1942 migration, :2427-2446 ghosts).
+   hmd_migrate_pack_slots_dev: hmd_migrate_pack in its fixed-size form (slot_rows >= 1; args->n and args->send_off are
+   ignored) with n = min(*d_n_leave, capacity) keys of the sorted key array and the per-rank counts d_rank_count[r]
+   (hmd_migrate_dest's outputs); places of the key array past the last key must hold a destination >= n_ranks.
+   hmd_pack_ghost_init_slots_dev: hmd_pack_ghost_init_slots (slots->off and slots->flag are ignored) with
+   n_send = min(*d_total, capacity) and the rows per destination rank summed from d_dir_count[k] over the directions k
+   with d_dir_dest[k] == rank (hmd_ghost_send_list's outputs; directions sorted by destination rank).
+   A list that outgrew its key array (*d_n_leave or *d_total above capacity) is incomplete; the sender says so in
+   every header -- migration: 0xffffffff in word 1 (the "largest count"); ghosts: bit 1 of the flag word (bit 0: a
+   message was too small) -- so that all ranks repeat the exchange together, the sender with a larger array.
+   With d_sorted_keys (the sorted keys direction << 32 | particle index) hmd_pack_ghost_init_slots_dev takes the send
+   list from the keys and stores it in args->d_send_idx / d_send_shift_id on the way (hmd_ghost_split_keys without a
+   launch of its own).
+   The *_and forms of the header kernels append n_extra (<= 64) words of d_extra behind the 2 * n_ranks header words,
+   so that one look of the host covers the headers that arrived and the counts that stayed; with d_published they
+   also publish every word, stamped, as hmd_publish_words would (one launch less before the host can look).
+   hmd_comm_prep zeroes n_counters words and fills n_keys keys with all ones, the padding that sorts behind every key
+   (the two memsets before hmd_migrate_dest / hmd_ghost_send_list in one launch). */
+int hmd_comm_prep(unsigned int* d_counters, unsigned int n_counters, unsigned long long* d_keys, unsigned int n_keys, void* stream);
+int hmd_migrate_pack_slots_dev(const hmd_migrate_pack_args_t* args, const unsigned int* d_n_leave, const unsigned int* d_rank_count,
+                               unsigned int capacity, void* stream);
+int hmd_migrate_slot_headers_and(const long long* d_in, unsigned int slot_rows, unsigned int n_ranks, const unsigned int* d_extra,
+                                 unsigned int n_extra, unsigned int* d_words, unsigned long long* d_published, unsigned int stamp, void* stream);
+int hmd_pack_ghost_init_slots_dev(const hmd_pack_pos_args_t* args, const unsigned int* d_tag, const hmd_ghost_slots_t* slots,
+                                  const unsigned int* d_total, const unsigned int* d_dir_count, const unsigned int* d_dir_dest, unsigned int n_dir,
+                                  unsigned int capacity, const unsigned long long* d_sorted_keys, void* stream);
+int hmd_ghost_slot_headers_and(const hmd_scalar4* d_in, const hmd_ghost_slots_t* slots, const unsigned int* d_extra, unsigned int n_extra,
+                               unsigned int* d_words, unsigned long long* d_published, unsigned int stamp, void* stream);
 
 /* Close the gaps the leavers leave: the N - n_leave staying particles end up in [0, N - n_leave).  Stayers
    behind that boundary move into the leavers' places in front of it (in the order of d_keys, which must be

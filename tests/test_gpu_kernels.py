@@ -1074,3 +1074,126 @@ def test_probe_tells_streams_that_run_beside_the_default_stream_from_those_behin
     assert sum(answers) >= 1
     o = C.c_int(-1)
     assert _abi.lib.hmd_stream_runs_beside_default(None, _abi.ptr(words), C.byref(o)) == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_packs_that_read_their_sizes_on_the_device(K, A):
+    """hmd_migrate_pack_slots_dev / hmd_pack_ghost_init_slots_dev write the very buffers hmd_migrate_pack /
+    hmd_pack_ghost_init_slots write when the host passes the counts in; a list that outgrew its key array is announced
+    in every header; the *_and header kernels hand the host headers and counts in one piece."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    # ---- migration ----
+    N, world, rank = 5000, 6, 3
+    glo, gL, grid, dec = np.array([-6.0, -7.0, -8.0]), np.array([12.0, 14.0, 16.0]), (2, 1, 3), (1, 0, 1)
+    lo = glo + np.array([1, 0, 1]) * gL / np.array(grid)
+    xyz = lo + rng.random((N, 3)) * gL / np.array(grid)
+    out = rng.random(N) < 0.1
+    xyz[out] += rng.normal(0, 4.0, (int(out.sum()), 3)) * np.array(dec)
+    dev = dict(pos=torch.from_numpy(orc.pack_pos(xyz, rng.integers(0, 3, N))).cuda(), vel=torch.from_numpy(rng.normal(size=(N, 4))).cuda(),
+               accel=torch.from_numpy(rng.normal(size=(N, 3))).cuda(), image=torch.from_numpy(rng.integers(-3, 4, (N, 3)).astype(np.int32)).cuda(),
+               tag=torch.from_numpy(rng.permutation(N).astype(np.int32)).cuda(), body=torch.full((N,), -1, dtype=torch.int32, device="cuda"),
+               charge=torch.from_numpy(rng.normal(size=N)).cuda(), diameter=torch.from_numpy(rng.random(N) + 0.5).cuda())
+    p = A.PDataArraysStruct()
+    p.d_pos, p.d_vel, p.d_accel, p.d_image = dev["pos"].data_ptr(), dev["vel"].data_ptr(), dev["accel"].data_ptr(), dev["image"].data_ptr()
+    p.d_tag, p.d_body, p.d_charge, p.d_diameter = dev["tag"].data_ptr(), dev["body"].data_ptr(), dev["charge"].data_ptr(), dev["diameter"].data_ptr()
+    dest = torch.zeros(N, dtype=torch.int32, device="cuda")
+    for cap in (2048, 64):   # roomy, and too small for the leavers
+        counters = torch.zeros(1 + world, dtype=torch.int32, device="cuda")
+        keys = torch.full((cap,), -1, dtype=torch.int64, device="cuda")   # all ones: a destination no rank has
+        a = A.MigrateDestArgs()
+        a.d_pos, a.N, a.rank = dev["pos"].data_ptr(), N, rank
+        a.global_lo[:], a.global_L[:], a.grid[:], a.decomposed[:] = list(glo), list(gL), list(grid), list(dec)
+        a.d_dest, a.d_n_leave, a.d_rank_count, a.n_ranks = dest.data_ptr(), counters.data_ptr(), counters.data_ptr() + 4, world
+        a.d_keys, a.capacity = keys.data_ptr(), cap
+        A.check(A.lib.hmd_migrate_dest(C.byref(a), None), "hmd_migrate_dest")
+        cnt = counters.cpu().numpy()
+        n_leave = int(cnt[0])
+        assert (n_leave <= cap) == (cap == 2048) and n_leave > 64
+        skeys = K.sort_keys(keys, 32 + 3)   # 3 bits hold ranks 0..5 and the padding's 7
+        assert (skeys.cpu().numpy()[min(n_leave, cap):] >> 32 & 7 == 7).all()
+        slot = int(cnt[1:].max()) + 2
+        pk = A.MigratePackArgs()
+        pk.arrays, pk.d_keys = p, skeys.data_ptr()
+        pk.global_lo[:], pk.global_L[:], pk.decomposed[:] = list(glo), list(gL), list(dec)
+        pk.slot_rows, pk.n_ranks = slot, world
+        got = torch.full((world * (slot + 1), A.MIGRATE_ROW_WORDS), -7, dtype=torch.int64, device="cuda")
+        pk.d_out = got.data_ptr()
+        A.check(A.lib.hmd_migrate_pack_slots_dev(C.byref(pk), counters.data_ptr(), counters.data_ptr() + 4, cap, None), "hmd_migrate_pack_slots_dev")
+        g = got.cpu().numpy().reshape(world, slot + 1, -1)
+        if n_leave <= cap:
+            want = torch.full_like(got, -7)
+            pk.d_out, pk.n = want.data_ptr(), n_leave
+            for r in range(world + 1):
+                pk.send_off[r] = int(cnt[1:1 + r].sum())
+            A.check(A.lib.hmd_migrate_pack(C.byref(pk), None), "hmd_migrate_pack")
+            assert torch.equal(got, want)
+        else:
+            assert (g[:, 0, 1] == 0xFFFFFFFF).all() and np.array_equal(g[:, 0, 0], cnt[1:])
+        words = torch.zeros(2 * world + 1 + world, dtype=torch.int32, device="cuda")
+        pub = torch.zeros(64, dtype=torch.int64, device="cuda")
+        A.check(A.lib.hmd_migrate_slot_headers_and(got.data_ptr(), slot, world, counters.data_ptr(), 1 + world, words.data_ptr(), pub.data_ptr(), 77, None), "headers")
+        assert np.array_equal(pub.cpu().numpy()[:len(words)], (77 << 32) | words.cpu().numpy().view(np.uint32).astype(np.int64))
+        w = words.cpu().numpy().view(np.uint32)
+        assert np.array_equal(w[0:2 * world:2], cnt[1:]) and np.array_equal(w[2 * world:], cnt.view(np.uint32))
+        assert (w[1:2 * world:2] == (0xFFFFFFFF if n_leave > cap else cnt[1:].max())).all()
+
+    # ---- ghost layer: rows per direction -> rows per destination rank, messages with room from last time ----
+    n_dir, world = 7, 4
+    dir_dest = np.array([0, 0, 1, 1, 1, 3, 3], dtype=np.int32)      # directions sorted by destination; nothing for rank 2
+    dir_count = rng.integers(0, 300, n_dir).astype(np.int32)
+    total = int(dir_count.sum())
+    Np = 4000
+    pos = orc.pack_pos(rng.normal(size=(Np, 3)) * 5, rng.integers(0, 4, Np))
+    tag = rng.permutation(Np).astype(np.int32)
+    table = rng.normal(size=(n_dir, 3))
+    pos_t, tag_t, table_t = torch.from_numpy(pos).cuda(), torch.from_numpy(tag).cuda(), torch.from_numpy(table).cuda()
+    rows = np.bincount(dir_dest, weights=dir_count, minlength=world).astype(np.int64)
+    for cap_keys, tight in ((total + 500, False), (total + 500, True), (total // 2, False)):
+        n_have = min(total, cap_keys)
+        send = torch.from_numpy(np.concatenate([rng.integers(0, Np, n_have), np.full(cap_keys - n_have, -1)]).astype(np.int32)).cuda()
+        sid = torch.from_numpy(np.concatenate([np.repeat(np.arange(n_dir), dir_count)[:n_have], np.full(cap_keys - n_have, 255)]).astype(np.uint8)).cuda()
+        s = A.GhostSlots()
+        s.n_ranks = world
+        row0 = 0
+        for r in range(world):
+            s.cap[r] = int(rows[r]) // 2 if (tight and r == 1) else int(rows[r]) + 10
+            s.row0[r] = row0
+            row0 += s.cap[r] + 1
+        counters = torch.from_numpy(np.concatenate([[total], dir_count]).astype(np.int32)).cuda()
+        dd = torch.from_numpy(dir_dest).cuda()
+        pa = A.PackPosArgs()
+        got = torch.full((row0, 4), -3.0, dtype=torch.float64, device="cuda")
+        pa.d_out, pa.d_pos, pa.d_send_idx, pa.d_send_shift_id, pa.d_shift_table = got.data_ptr(), pos_t.data_ptr(), send.data_ptr(), sid.data_ptr(), table_t.data_ptr()
+        A.check(A.lib.hmd_pack_ghost_init_slots_dev(C.byref(pa), tag_t.data_ptr(), C.byref(s), counters.data_ptr(), counters.data_ptr() + 4, dd.data_ptr(), n_dir,
+                                                    cap_keys, None, None), "hmd_pack_ghost_init_slots_dev")
+        # the same with the send list taken from sorted keys (and stored on the way)
+        skeys = ((sid.to(torch.int64) << 32) | (send.to(torch.int64) & 0xFFFFFFFF)).contiguous()
+        send2, sid2, got2 = torch.zeros_like(send), torch.zeros_like(sid), torch.full_like(got, -3.0)
+        pa.d_out, pa.d_send_idx, pa.d_send_shift_id = got2.data_ptr(), send2.data_ptr(), sid2.data_ptr()
+        A.check(A.lib.hmd_pack_ghost_init_slots_dev(C.byref(pa), tag_t.data_ptr(), C.byref(s), counters.data_ptr(), counters.data_ptr() + 4, dd.data_ptr(), n_dir,
+                                                    cap_keys, skeys.data_ptr(), None), "hmd_pack_ghost_init_slots_dev")
+        assert torch.equal(got2.view(torch.int64), got.view(torch.int64))
+        assert torch.equal(send2[:n_have], send[:n_have]) and torch.equal(sid2[:n_have], sid[:n_have])
+        pa.d_out, pa.d_send_idx, pa.d_send_shift_id = got.data_ptr(), send.data_ptr(), sid.data_ptr()
+        flag = (1 if tight else 0) | (2 if total > cap_keys else 0)
+        hdr = got.cpu().numpy().view(np.uint64)
+        for r in range(world):
+            assert int(hdr[s.row0[r], 0]) == rows[r] and int(hdr[s.row0[r], 1]) == flag
+        if total <= cap_keys:
+            want = torch.full_like(got, -3.0)
+            pa.d_out, pa.n_send = want.data_ptr(), total
+            s.flag = flag
+            for r in range(world + 1):
+                s.off[r] = int(rows[:r].sum())
+            A.check(A.lib.hmd_pack_ghost_init_slots(C.byref(pa), tag_t.data_ptr(), C.byref(s), None), "hmd_pack_ghost_init_slots")
+            assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+        words = torch.zeros(2 * world + 1 + n_dir, dtype=torch.int32, device="cuda")
+        A.check(A.lib.hmd_ghost_slot_headers_and(got.data_ptr(), C.byref(s), counters.data_ptr(), 1 + n_dir, words.data_ptr(), None, 0, None), "headers")
+        w = words.cpu().numpy()
+        assert np.array_equal(w[0:2 * world:2], rows) and (w[1:2 * world:2] == flag).all() and np.array_equal(w[2 * world:], counters.cpu().numpy())
+    assert A.lib.hmd_migrate_pack_slots_dev(None, None, None, 0, None) == A.ERR_INVALID_ARGUMENT
+    # counters to zero and keys to the padding in one launch
+    c = torch.full((9,), 5, dtype=torch.int32, device="cuda")
+    k = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    A.check(A.lib.hmd_comm_prep(c.data_ptr(), 7, k.data_ptr(), 999, None), "hmd_comm_prep")
+    assert c.cpu().tolist() == [0] * 7 + [5, 5] and (k[:999] == -1).all() and int(k[999]) == 0
