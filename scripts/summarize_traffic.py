@@ -63,7 +63,7 @@ for k, r in rows.items():
     ws = cal["write_scale"] or 1.0
     r["hbm_bytes_per_launch"] = (r["fetch_kb"] * rs + r["write_kb"] * ws) * 1024.0
     r["hbm_bytes_per_particle"] = r["hbm_bytes_per_launch"] / N
-summary = {"N": N, "calibration": cal, "kernels": rows,
+summary = {"N": N, "workload": "lj", "calibration": cal, "kernels": rows,
            "note": "FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; scales calibrated on the stand-alone second half step "
                    "(known streaming byte count) in the same runs"}
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
