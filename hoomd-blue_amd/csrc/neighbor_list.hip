@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include "tile.cuh"
 
 namespace
@@ -597,6 +598,18 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             band_all = max(band_all, __float_as_uint(pf.hi) - __float_as_uint(pf.lo));
         }
 
+    // One type: the same two decisions from a float difference, two slabs per instruction.  d = r32 - lo', lo' the float
+    // after lo: the difference of two floats has the sign of the exact difference (it is never rounded to zero), so the
+    // sign bit of d is set exactly for r32 <= lo; and 0 <= d <= hi - lo' (as bit patterns: below bits(band_f), band_f a
+    // little above hi - lo) covers every r32 in (lo, hi].
+    const nl_v2f lo_next2 = {__uint_as_float(lo1_tp[0]), __uint_as_float(lo1_tp[0])};
+    unsigned int band_f_bits = 0;
+        {
+        const nl_pref_t pf0 = nl_pref_thresholds(HMD_ADD(a.d_r_cut[0], a.r_buff), rl2_tp[0], wmax);
+        if (pf0.hi > 0.0f)
+            band_f_bits = __float_as_uint((pf0.hi - pf0.lo) * 1.001f + 1.0e-30f);
+        }
+
     const unsigned int cells_per_block = NL_WAVES / wpc;
     const unsigned int vb = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned int cell = vb * cells_per_block + wave / wpc;
@@ -875,8 +888,18 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             // 16-bit slabs count of this pass and the fp32 thresholds as integers: for non-negative floats the bit
             // patterns order like the values, so t = bits(r32) - (bits(lo) + 1) is negative (top bit set) exactly for
             // r32 <= lo, and below `band` exactly for lo < r32 <= hi
-            const unsigned int nslab = (Tp + 63u) / 64u;
+            const unsigned int nslab_dyn = (Tp + 63u) / 64u;
             const unsigned int band = band_all;
+            // The walk over the home particles, written once and compiled for the slab counts cells of a liquid have
+            // (NS = 8 ... MAXK: every 'is slab c in use' below is then decided by the compiler and the loops over the slabs
+            // are straight-line code) and once more with the count read at run time (NS = 0).  The kernel spends its time
+            // waiting on its own instruction stream, not on the vector units: some sixty scalar compare-and-branch pairs
+            // per home particle, half of them taken, were most of that stream.
+            auto walk = [&](auto ns_tag)
+            {
+            constexpr unsigned int NS = decltype(ns_tag)::value;
+            const unsigned int nslab = NS ? NS : nslab_dyn;
+            auto live = [&](int c) -> bool { return NS ? (unsigned int)c < NS : (unsigned int)(c * 64) < Tp; };
             for (unsigned int i = sub; i < nh; i += wpc)
                 {
                 const unsigned int iu = __builtin_amdgcn_readfirstlane(i);
@@ -905,18 +928,32 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
 #pragma unroll
                     for (int s = 0; s < (MAXK / 2); s++)
                         {
-                        if ((unsigned int)(2 * s * 64) < Tp)
+                        if (live(2 * s))
                             {
                             const nl_v2f dx = px - fx[s], dy = py - fy[s], dz = pz - fz[s];
                             nl_v2f r = dx * dx;
                             r = __builtin_elementwise_fma(dy, dy, r);
                             r = __builtin_elementwise_fma(dz, dz, r);
+                            if constexpr (!TWO)
+                                {
+                                const nl_v2f d = r - lo_next2;
+                                const unsigned int d0 = __float_as_uint(d.x), d1 = __float_as_uint(d.y);
+                                bits = __builtin_amdgcn_alignbit(bits, d0, 31);
+                                if (live(2 * s + 1))
+                                    {
+                                    bits = __builtin_amdgcn_alignbit(bits, d1, 31);
+                                    nearest = min(nearest, min(d0, d1)); // (one three-operand minimum)
+                                    }
+                                else
+                                    nearest = min(nearest, d0);
+                                continue;
+                                }
                             unsigned int t0 = __float_as_uint(r.x) - lo1;
                             if (TWO)
                                 t0 -= (unsigned int)__builtin_amdgcn_sbfe((int)ctbits, 2 * s, 1) & lo1_d;
                             bits = __builtin_amdgcn_alignbit(bits, t0, 31);
                             nearest = min(nearest, t0);
-                            if ((unsigned int)((2 * s + 1) * 64) < Tp)
+                            if (live(2 * s + 1))
                                 {
                                 unsigned int t1 = __float_as_uint(r.y) - lo1;
                                 if (TWO)
@@ -927,7 +964,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                             }
                         }
                     }
-                if (__ballot(nearest < band))
+                if (__ballot(nearest < (TWO ? band : band_f_bits)))
                     {
                     // a candidate of this particle sits in the band around r_list^2: every slab again with the CPU
                     // path's own arithmetic -- the difference first, then the box length of the image
@@ -964,7 +1001,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     {
 #pragma unroll
                         for (int c = 0; c < MAXK; c++)
-                            if ((unsigned int)(c * 64) < Tp && (TILE ? cidx[c] : co[c]) == e)
+                            if (live(c) && (TILE ? cidx[c] : co[c]) == e)
                                 bits &= ~(1u << (nslab - 1u - (unsigned int)c));
                     };
 #pragma unroll
@@ -988,27 +1025,34 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     {
                     // the slab bits leave through the top of the register one by one; the running position steps
                     // forward on every hit
+                    // Two vector instructions per slab: b + b shifts the next bit out through the carry, and under the
+                    // lanes the carry selects the row address steps forward by one entry and the entry is stored
+                    // (in assembly: the compiler has no way to say "branch on the carry of this addition").
                     unsigned int b = bits << (32u - nslab);
-                    unsigned int pos = base - 1u;
+                    unsigned int addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)wrow + 4u * base - 4u;
+                    unsigned long long saved_exec;
 #pragma unroll
                     for (int c = 0; c < MAXK; c++)
                         {
-                        if ((unsigned int)(c * 64) < Tp)
-                            {
-                            const bool hit = (int)b < 0;
-                            b <<= 1;
-                            pos += hit ? 1u : 0u;
-                            if (hit)
-                                wrow[pos] = co[c];
-                            }
+                        if (live(c))
+                            asm volatile("v_add_co_u32_e32 %0, vcc, %0, %0\n\t"
+                                         "s_and_saveexec_b64 %2, vcc\n\t"
+                                         "v_add_u32_e32 %1, 4, %1\n\t"
+                                         "ds_write_b32 %1, %3\n\t"
+                                         "s_or_b64 exec, exec, %2"
+                                         : "+v"(b), "+v"(addr), "=&s"(saved_exec)
+                                         : "v"(co[c])
+                                         : "vcc", "memory");
                         }
+                    // (the stores above are invisible to the compiler's own count of outstanding LDS operations)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                 else
                     {
 #pragma unroll
                     for (int c = 0; c < MAXK; c++)
                         {
-                        if ((unsigned int)(c * 64) < Tp)
+                        if (live(c))
                             {
                             const unsigned int bp = nslab - 1u - (unsigned int)c;
                             const unsigned int pos = base + (unsigned int)__popc(bits >> 1 >> bp); // this lane's hits in earlier slabs sit above bit bp
@@ -1070,6 +1114,39 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     }
                 if (lane == iu)
                     cnt = cnt_new;
+                }
+            };
+            switch (nslab_dyn)
+                {
+            case 8:
+                walk(std::integral_constant<unsigned int, 8> {});
+                break;
+            case 9:
+                walk(std::integral_constant<unsigned int, 9> {});
+                break;
+            case 10:
+                walk(std::integral_constant<unsigned int, 10> {});
+                break;
+            case 11:
+                walk(std::integral_constant<unsigned int, 11> {});
+                break;
+            case 12:
+                walk(std::integral_constant<unsigned int, 12> {});
+                break;
+            case 13:
+                if constexpr (MAXK >= 13)
+                    walk(std::integral_constant<unsigned int, 13> {});
+                else
+                    walk(std::integral_constant<unsigned int, 0> {});
+                break;
+            case 14:
+                if constexpr (MAXK >= 14)
+                    walk(std::integral_constant<unsigned int, 14> {});
+                else
+                    walk(std::integral_constant<unsigned int, 0> {});
+                break;
+            default:
+                walk(std::integral_constant<unsigned int, 0> {});
                 }
             }
 

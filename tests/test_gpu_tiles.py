@@ -201,8 +201,12 @@ def test_tile_forces_with_densely_filled_cells(K, A, ntypes):
                                    np.zeros_like(rcutsq), shift_mode=0, third_law=True, compute_virial=True)
     F, V = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, np.zeros_like(rcutsq), shift_mode=0, compute_virial=True)
     F2, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, params, rcutsq, np.zeros_like(rcutsq), shift_mode=0, compute_virial=False)
-    assert _rel_err(F.cpu().numpy(), F_ref) < F_RTOL * 1e-4 and _rel_err(V.cpu().numpy(), V_ref) < F_RTOL * 1e-4
-    assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
+    # At this density single pair terms are 1e4 to 1e5 times a net force component, and the order of the sum follows the
+    # order of a cell's members, which the cell list's slot counters decide anew in every run: rounding alone moves a
+    # component by 1e-11 to 1e-10 of its value, so the bound here is 1e-9 (a missed or doubled pair shows at 1e-5).
+    tol = F_RTOL * 1e-3
+    assert _rel_err(F.cpu().numpy(), F_ref) < tol and _rel_err(V.cpu().numpy(), V_ref) < tol
+    assert _rel_err(F2.cpu().numpy(), F_ref) < tol
 
 
 def test_tile_path_limits_are_reported(K, A):
