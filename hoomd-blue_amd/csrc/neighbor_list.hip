@@ -599,9 +599,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         }
 
     // One type: the same two decisions from a float difference, two slabs per instruction.  d = r32 - lo', lo' the float
-    // after lo: the difference of two floats has the sign of the exact difference (it is never rounded to zero), so the
-    // sign bit of d is set exactly for r32 <= lo; and 0 <= d <= hi - lo' (as bit patterns: below bits(band_f), band_f a
-    // little above hi - lo) covers every r32 in (lo, hi].
+    // after lo, accumulated as dz^2 + (dy^2 + (dx^2 - lo')) in three fused operations: a negative d (sign bit set) is a
+    // candidate inside r_list whatever the roundings did, 0 <= d < band_f (as bit patterns; band_f a little above
+    // hi - lo) is undecided, anything above is outside.
     const nl_v2f lo_next2 = {__uint_as_float(lo1_tp[0]), __uint_as_float(lo1_tp[0])};
     unsigned int band_f_bits = 0;
         {
@@ -724,6 +724,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         s_tileoff[lane] = __shfl(rincl - rsize, (int)rc);
         }
     const unsigned int T = rl_u(incl, 63);
+    unsigned short* const trow_block = TILE ? d_tile + (size_t)tile_grp0 * hmd::tile_group_entries(row_pieces) : nullptr;
 
     // candidate k of the list: its cell-list slot, the shift of its cell's image, what a row stores for it
     auto cand_lookup = [&](unsigned int k, unsigned int& lo) -> unsigned int
@@ -931,23 +932,31 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         if (live(2 * s))
                             {
                             const nl_v2f dx = px - fx[s], dy = py - fy[s], dz = pz - fz[s];
-                            nl_v2f r = dx * dx;
-                            r = __builtin_elementwise_fma(dy, dy, r);
-                            r = __builtin_elementwise_fma(dz, dz, r);
                             if constexpr (!TWO)
                                 {
-                                const nl_v2f d = r - lo_next2;
+                                // r32 - lo' in one chain of three fused operations, the subtraction first: every
+                                // intermediate of a candidate near the threshold is at most r_list^2 in size, so the
+                                // three roundings stay within the 3 u r_list^2 the thresholds allow for the arithmetic
+                                // (a result of exactly zero counts as undecided)
+                                nl_v2f d = __builtin_elementwise_fma(dx, dx, -lo_next2);
+                                d = __builtin_elementwise_fma(dy, dy, d);
+                                d = __builtin_elementwise_fma(dz, dz, d);
                                 const unsigned int d0 = __float_as_uint(d.x), d1 = __float_as_uint(d.y);
                                 bits = __builtin_amdgcn_alignbit(bits, d0, 31);
                                 if (live(2 * s + 1))
                                     {
                                     bits = __builtin_amdgcn_alignbit(bits, d1, 31);
-                                    nearest = min(nearest, min(d0, d1)); // (one three-operand minimum)
+                                    // (one three-operand minimum; left to itself the compiler pairs up the slabs' minima
+                                    // first, which costs half as many instructions again)
+                                    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(nearest) : "v"(d0), "v"(d1));
                                     }
                                 else
                                     nearest = min(nearest, d0);
                                 continue;
                                 }
+                            nl_v2f r = dx * dx;
+                            r = __builtin_elementwise_fma(dy, dy, r);
+                            r = __builtin_elementwise_fma(dz, dz, r);
                             unsigned int t0 = __float_as_uint(r.x) - lo1;
                             if (TWO)
                                 t0 -= (unsigned int)__builtin_amdgcn_sbfe((int)ctbits, 2 * s, 1) & lo1_d;
@@ -1076,8 +1085,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 const unsigned int stop = min(min(cnt_new, nmax_w), (unsigned int)NL_ROWBUF);
                 if (TILE)
                     {
+                    // (the block's rows start at trow_block; within a block the offset of a row fits 32 bits)
                     const unsigned int h_i = tile_hoff + hbase + iu;
-                    char* trow = reinterpret_cast<char*>(d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE);
+                    char* trow = reinterpret_cast<char*>(trow_block + ((h_i / hmd::TL_GROUP) * (unsigned int)hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE));
                     if (fits && cnt_old == 0)
                         {
                         // one store instruction: every lane packs two entries, the padding to a multiple of four included
@@ -1085,7 +1095,10 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         const unsigned int e = 2u * lane;
                         if (e < padded)
                             {
-                            const uint2 w2 = *reinterpret_cast<const uint2*>(wrow + e);
+                            // (one 8-byte read whatever the row's length: asked for entry by entry the compiler reads each
+                            // under its own condition, one round trip to LDS after the other)
+                            const unsigned long long w = *reinterpret_cast<const volatile unsigned long long*>(wrow + e);
+                            const uint2 w2 = make_uint2((unsigned int)w, (unsigned int)(w >> 32));
                             const unsigned int v0 = e < cnt_new ? w2.x : tile_pad, v1 = e + 1u < cnt_new ? w2.y : tile_pad;
                             *reinterpret_cast<unsigned int*>(trow + (((lane >> 3) << 9) | ((lane & 7u) << 2))) = (v0 & 0xffffu) | (v1 << 16);
                             }
