@@ -554,8 +554,10 @@ __host__ __device__ constexpr unsigned int nl_pref_flag_bytes(unsigned int cell_
     return (27u * cell_Nmax + 63u) / 64u * 64u + 64u;
     }
 
+// (two types, tile rows: held to the registers of three waves per SIMD -- left alone the 14-slab version takes 180 and runs
+// two)
 template<bool TILE, bool EXCL, bool TWO, int MAXK>
-__global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
+__global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu((TILE && TWO && !EXCL) ? 3 : 1))) nlist_pref_kernel(hmd_nlist_binned_args_t a, unsigned int ncells, unsigned int wpc, double wmax, unsigned short* d_tile,
                                                               unsigned int tile_capacity, unsigned int* d_tile_overflow, hmd_uint4* d_slot_meta,
                                                               unsigned int* d_slot_of, hmd_scalar4* d_cpos, const unsigned int* d_block_group,
                                                               unsigned int row_pieces, nl_excl_t ex)
@@ -599,9 +601,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         }
 
     // One type: the same two decisions from a float difference, two slabs per instruction.  d = r32 - lo', lo' the float
-    // after lo, accumulated as dz^2 + (dy^2 + (dx^2 - lo')) in three fused operations: a negative d (sign bit set) is a
-    // candidate inside r_list whatever the roundings did, 0 <= d < band_f (as bit patterns; band_f a little above
-    // hi - lo) is undecided, anything above is outside.
+    // after lo: the difference of two floats has the sign of the exact difference (it is never rounded to zero), so the
+    // sign bit of d is set exactly for r32 <= lo; and 0 <= d <= hi - lo' (as bit patterns: below bits(band_f), band_f a
+    // little above hi - lo) covers every r32 in (lo, hi].
     const nl_v2f lo_next2 = {__uint_as_float(lo1_tp[0]), __uint_as_float(lo1_tp[0])};
     unsigned int band_f_bits = 0;
         {
@@ -745,6 +747,11 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         const unsigned int nh = min(n_home - hbase, 64u);
         double hx = 0, hy = 0, hz = 0;
         unsigned int hidx = 0xffffffffu, hnmax = 0, cnt = 0, htype = 0;
+        // Tile rows for two types are laid out by type: the neighbors of type 0 (cnt of them), the dummy up to a multiple of
+        // four entries, then the neighbors of type 1 (cntB) -- every chunk of four entries that a lane of the force kernel
+        // takes then has ONE type, and the kernel picks its parameters per chunk instead of per pair.
+        constexpr bool BY_TYPE = TWO && TILE;
+        unsigned int cntB = 0;
         // (the start of a home particle's row, the number of its exclusions and the first four of them are fetched here,
         // one home particle per lane, and handed out by lane reads in the loop below: fetched where they are used, each
         // was a round trip to memory that the whole wave waited for)
@@ -788,8 +795,17 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         const float hxf = (float)(hx - Ox), hyf = (float)(hy - Oy), hzf = (float)(hz - Oz);
 
         unsigned int cells_before = 0; // non-empty cells that start before the slab being looked up (slabs are taken in order)
-        for (unsigned int pbase = 0; pbase < T; pbase += MAXK * 64)
+        // The candidates are taken in passes of MAXK slabs (one pass is the rule).  Rows laid out by type need all
+        // neighbors of type 0 before the first of type 1: a cell with more candidates than one pass holds is swept twice,
+        // first for the hits of type 0 (mode 1), then for those of type 1 (mode 2); mode 0 places both at once.
+        const unsigned int npass = (T + (unsigned int)(MAXK * 64) - 1u) / (unsigned int)(MAXK * 64);
+        const unsigned int nsweep = (BY_TYPE && npass > 1u) ? 2u : 1u;
+        for (unsigned int it = 0; it < npass * nsweep; it++)
             {
+            const unsigned int pbase = (it % npass) * (unsigned int)(MAXK * 64);
+            const unsigned int mode = nsweep == 2u ? 1u + it / npass : 0u;
+            if (it % npass == 0u)
+                cells_before = 0;
             const unsigned int Tp = __builtin_amdgcn_readfirstlane(min(T - pbase, (unsigned int)(MAXK * 64)));
             nl_v2f fx[(MAXK / 2)], fy[(MAXK / 2)], fz[(MAXK / 2)];
             unsigned int co[MAXK]; // what a row stores for the candidate: tile slot or particle index
@@ -891,6 +907,8 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
             // r32 <= lo, and below `band` exactly for lo < r32 <= hi
             const unsigned int nslab_dyn = (Tp + 63u) / 64u;
             const unsigned int band = band_all;
+            // the candidates' type bits in the order of the hit words (slab c at bit nslab - 1 - c)
+            const unsigned int tbr = BY_TYPE ? (__brev(ctbits) >> (32u - nslab_dyn)) : 0u;
             // The walk over the home particles, written once and compiled for the slab counts cells of a liquid have
             // (NS = 8 ... MAXK: every 'is slab c in use' below is then decided by the compiler and the loops over the slabs
             // are straight-line code) and once more with the count read at run time (NS = 0).  The kernel spends its time
@@ -912,7 +930,9 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                 const nl_v2f px = {pxs, pxs}, py = {pys, pys}, pz = {pzs, pzs};
                 const unsigned int nmax_i = rl_u(hnmax, iu);
                 const unsigned int cnt_old = rl_u(cnt, iu);
-                const unsigned int nmax_w = TILE ? min(nmax_i, tile_row_cap) : nmax_i;
+                // (a row laid out by type holds up to three entries of the dummy between its parts: room for them beyond
+                // the capacity the overflow protocol counts in, which stays the reference's)
+                const unsigned int nmax_w = TILE ? min(nmax_i + (BY_TYPE ? 3u : 0u), tile_row_cap) : nmax_i;
                 const size_t row_head = TILE ? 0 : (((size_t)rl_u(hhead_hi, iu) << 32) | (size_t)rl_u(hhead_lo, iu));
                 // thresholds of this particle's type against candidates of type 0 and 1
                 const unsigned int ti = TWO ? rl_u(htype, iu) : 0u;
@@ -934,13 +954,13 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                             const nl_v2f dx = px - fx[s], dy = py - fy[s], dz = pz - fz[s];
                             if constexpr (!TWO)
                                 {
-                                // r32 - lo' in one chain of three fused operations, the subtraction first: every
-                                // intermediate of a candidate near the threshold is at most r_list^2 in size, so the
-                                // three roundings stay within the 3 u r_list^2 the thresholds allow for the arithmetic
-                                // (a result of exactly zero counts as undecided)
-                                nl_v2f d = __builtin_elementwise_fma(dx, dx, -lo_next2);
-                                d = __builtin_elementwise_fma(dy, dy, d);
-                                d = __builtin_elementwise_fma(dz, dz, d);
+                                // (the threshold folded into the chain, fma(dx, dx, -lo') first, saves an instruction per two
+                                // slabs and 3 % of the kernel run by itself -- and cost 6 % of the time step in the
+                                // simulation, measured back to back on one box; left out)
+                                nl_v2f r = dx * dx;
+                                r = __builtin_elementwise_fma(dy, dy, r);
+                                r = __builtin_elementwise_fma(dz, dz, r);
+                                const nl_v2f d = r - lo_next2;
                                 const unsigned int d0 = __float_as_uint(d.x), d1 = __float_as_uint(d.y);
                                 bits = __builtin_amdgcn_alignbit(bits, d0, 31);
                                 if (live(2 * s + 1))
@@ -1021,6 +1041,117 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                         leave_out(__builtin_amdgcn_readfirstlane(ex.d_ex_list[hmd_idx2(ex.exli, i_idx, o)]));
                     }
 
+                if constexpr (BY_TYPE)
+                    {
+                    // ---- compaction by type: one scan carries both counts (low and high half of a word) ----
+                    const unsigned int bA = mode == 2u ? 0u : bits & ~tbr, bB = mode == 1u ? 0u : bits & tbr;
+                    const unsigned int mA = (unsigned int)__popc(bA), mB = (unsigned int)__popc(bB);
+                    const unsigned int inc = nl_wave_scan_dpp(mA | (mB << 16));
+                    const unsigned int tot = rl_u(inc, 63);
+                    const unsigned int hA = tot & 0xffffu, hB = tot >> 16;
+                    const unsigned int cB_old = rl_u(cntB, iu);
+                    const unsigned int cA_new = cnt_old + hA;
+                    const unsigned int nA4 = (cA_new + 3u) & ~3u; // (final in modes 0 and 2)
+                    const unsigned int baseA = cnt_old + (inc & 0xffffu) - mA;
+                    const unsigned int baseB = nA4 + cB_old + (inc >> 16) - mB;
+                    const unsigned int lay_new = mode == 1u ? cA_new : nA4 + cB_old + hB; // entries of the row laid out so far
+                    const unsigned int lay_lo = mode == 2u ? nA4 + cB_old : cnt_old;      // the first one this pass writes
+                    unsigned int* wrow = s_rowbuf + NL_ROWBUF * wave;
+                    const unsigned int h_i = tile_hoff + hbase + iu;
+                    unsigned short* trow16 = trow_block + ((h_i / hmd::TL_GROUP) * (unsigned int)hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE);
+                    char* trow = reinterpret_cast<char*>(trow16);
+                    const bool fits = mode == 0u && lay_new <= min(nmax_w, (unsigned int)NL_ROWBUF);
+                    if (fits)
+                        {
+                        // (as below, once per type; cnt_old and cB_old are zero in mode 0)
+                        unsigned long long saved_exec;
+                        unsigned int b = bA << (32u - nslab);
+                        unsigned int addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)wrow + 4u * baseA - 4u;
+#pragma unroll
+                        for (int c = 0; c < MAXK; c++)
+                            {
+                            if (live(c))
+                                asm volatile("v_add_co_u32_e32 %0, vcc, %0, %0\n\t"
+                                             "s_and_saveexec_b64 %2, vcc\n\t"
+                                             "v_add_u32_e32 %1, 4, %1\n\t"
+                                             "ds_write_b32 %1, %3\n\t"
+                                             "s_or_b64 exec, exec, %2"
+                                             : "+v"(b), "+v"(addr), "=&s"(saved_exec)
+                                             : "v"(co[c])
+                                             : "vcc", "memory");
+                            }
+                        b = bB << (32u - nslab);
+                        addr = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)wrow + 4u * baseB - 4u;
+#pragma unroll
+                        for (int c = 0; c < MAXK; c++)
+                            {
+                            if (live(c))
+                                asm volatile("v_add_co_u32_e32 %0, vcc, %0, %0\n\t"
+                                             "s_and_saveexec_b64 %2, vcc\n\t"
+                                             "v_add_u32_e32 %1, 4, %1\n\t"
+                                             "ds_write_b32 %1, %3\n\t"
+                                             "s_or_b64 exec, exec, %2"
+                                             : "+v"(b), "+v"(addr), "=&s"(saved_exec)
+                                             : "v"(co[c])
+                                             : "vcc", "memory");
+                            }
+                        if (lane < nA4 - cA_new)
+                            wrow[cA_new + lane] = tile_pad; // the dummy between the two parts
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const unsigned int padded = (lay_new + 3u) & ~3u;
+                        const unsigned int e = 2u * lane;
+                        if (e < padded)
+                            {
+                            const unsigned long long w = *reinterpret_cast<const volatile unsigned long long*>(wrow + e);
+                            const unsigned int w0 = (unsigned int)w, w1 = (unsigned int)(w >> 32);
+                            const unsigned int v0 = e < lay_new ? w0 : tile_pad, v1 = e + 1u < lay_new ? w1 : tile_pad;
+                            *reinterpret_cast<unsigned int*>(trow + (((lane >> 3) << 9) | ((lane & 7u) << 2))) = (v0 & 0xffffu) | (v1 << 16);
+                            }
+                        }
+                    else
+                        {
+                        // long rows and cells swept in several passes: every hit finds its place by counting
+                        auto put = [&](unsigned int pos, unsigned int what)
+                        {
+                            if (pos < nmax_w)
+                                {
+                                if (pos < (unsigned int)NL_ROWBUF)
+                                    wrow[pos] = what;
+                                else
+                                    trow16[((pos & ~15u) << 4) | (pos & 15u)] = (unsigned short)what;
+                                }
+                        };
+#pragma unroll
+                        for (int c = 0; c < MAXK; c++)
+                            {
+                            if (live(c))
+                                {
+                                const unsigned int bp = nslab - 1u - (unsigned int)c;
+                                if ((bA >> bp) & 1u)
+                                    put(baseA + (unsigned int)__popc(bA >> 1 >> bp), co[c]);
+                                if ((bB >> bp) & 1u)
+                                    put(baseB + (unsigned int)__popc(bB >> 1 >> bp), co[c]);
+                                }
+                            }
+                        // (the dummy between the parts: here when both parts are placed at once, after the sweeps otherwise)
+                        if (mode == 0u && lane < nA4 - cA_new)
+                            put(cA_new + lane, tile_pad);
+                        const unsigned int stop = min(min(lay_new, nmax_w), (unsigned int)NL_ROWBUF);
+#pragma unroll
+                        for (unsigned int e0 = 0; e0 < (unsigned int)NL_ROWBUF; e0 += 64)
+                            {
+                            const unsigned int e = e0 + lane;
+                            if (e >= lay_lo && e < stop)
+                                *reinterpret_cast<unsigned short*>(trow + (((e & ~15u) << 5) | ((e & 15u) << 1))) = (unsigned short)wrow[e];
+                            }
+                        }
+                    if (lane == iu)
+                        {
+                        cnt = cA_new;
+                        cntB = cB_old + hB;
+                        }
+                    continue;
+                    }
                 // ---- compaction: hits ordered by lane, then slab.  One scan over the wave places every lane's hits. ----
                 const unsigned int mine = (unsigned int)__popc(bits);
                 const unsigned int incl = nl_wave_scan_dpp(mine);
@@ -1179,6 +1310,11 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
         if (lane < nh && hidx < a.N && (lane % wpc) == sub)
             {
             const double wtype = a.d_pos[hidx].w;
+            // rows laid out by type: what the row holds (the dummy entries between the parts included) and what it lists
+            const unsigned int n_first = cnt, n_first4 = (cnt + 3u) & ~3u;
+            const unsigned int n_listed = BY_TYPE ? cnt + cntB : cnt;
+            if (BY_TYPE)
+                cnt = n_first4 + cntB;
             if (TILE && d_slot_meta)
                 {
                 hmd_uint4 m = {hidx, cnt, 0u, 0u};
@@ -1190,18 +1326,27 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_pref_kernel(hmd_nlist_binned_a
                     hmd_st4(d_cpos + w, hx, hy, hz, wtype);
                     }
                 }
-            a.d_n_neigh[hidx] = cnt;
+            a.d_n_neigh[hidx] = n_listed;
             if (TILE)
                 {
                 const unsigned int h_i = tile_hoff + hbase + lane;
                 unsigned short* trow = d_tile + (size_t)(tile_grp0 + h_i / hmd::TL_GROUP) * hmd::tile_group_entries(row_pieces) + (h_i % hmd::TL_GROUP) * hmd::TL_PIECE;
-                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < min(hnmax, tile_row_cap); k++)
+                // (whole chunks of four: the force kernel evaluates the last chunk of a row to its end)
+                const unsigned int room = min((hnmax + (BY_TYPE ? 3u : 0u) + 3u) & ~3u, tile_row_cap);
+                for (unsigned int k = cnt; k < ((cnt + 3u) & ~3u) && k < room; k++)
                     trow[((k & ~15u) << 4) | (k & 15u)] = (unsigned short)tile_pad;
+                // (cells swept once per type: the dummy between the parts was not placed with the hits)
+                if (BY_TYPE && nsweep == 2u)
+                    for (unsigned int k = n_first; k < n_first4 && k < room; k++)
+                        trow[((k & ~15u) << 4) | (k & 15u)] = (unsigned short)tile_pad;
+                // rows with too few pieces for the dummy entries (row_pieces sized without them): reported as an overflow
+                if (BY_TYPE && n_listed < hnmax && cnt > min(hnmax + 3u, tile_row_cap))
+                    atomicMax(&a.d_conditions[htype], hnmax + 1u);
                 }
             if (a.d_last_updated_pos)
                 hmd_st4(a.d_last_updated_pos + hidx, hx, hy, hz, hmd_uint_as_double(hmd_double_as_uint(wtype)));
-            if (cnt >= hnmax)
-                atomicMax(&a.d_conditions[htype], cnt);
+            if (n_listed >= hnmax)
+                atomicMax(&a.d_conditions[htype], n_listed);
             }
         }
     }
@@ -2142,6 +2287,16 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     const nl_excl_t ex = {t.d_n_ex_idx, t.d_ex_list_idx, t.exli};
     return nlist_binned_driver(a, (hipStream_t)stream, t.d_tile_nlist, t.geom.capacity, t.d_tile_overflow, t.d_slot_meta, t.d_slot_of,
                                t.d_slot_of ? const_cast<hmd_scalar4*>(t.geom.d_cpos) : nullptr, t.geom.d_block_group, t.geom.row_pieces, ex);
+    }
+
+// The build with the pre-test is the one that lays rows out by type (launch_nlist: two types, no body filter -- tile rows
+// never have one --, orthorhombic, the 27-cell stencil with at least three cells per periodic direction that
+// hmd_compute_nlist_tiles requires anyway).
+extern "C" int hmd_nlist_tiles_rows_by_type(const hmd_nlist_tiles_args_t* args)
+    {
+    if (!args)
+        return 0;
+    return (args->ntypes == 2 && hmd_box_is_ortho(args->box) && !std::getenv("HOOMD_AMD_NLIST_EXACT_ONLY")) ? 1 : 0;
     }
 
 extern "C" size_t hmd_nlist_tiles_storage_entries(const hmd_index3d_t* ci, unsigned int n_members, unsigned int row_pieces)

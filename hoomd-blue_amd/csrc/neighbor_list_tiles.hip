@@ -41,10 +41,26 @@ __global__ void __launch_bounds__(TL_THREADS) tiles_to_rows_kernel(hmd_tiles_to_
                 continue;
             const unsigned int h = hfirst + s;
             const unsigned short* trow = a.d_tile_nlist + (size_t)(grp0 + h / TL_GROUP) * tile_group_entries(a.geom.row_pieces) + (h % TL_GROUP) * TL_PIECE;
-            const unsigned int n = min(a.d_n_neigh[i], a.geom.row_pieces * TL_PIECE);
+            const unsigned int cap = a.geom.row_pieces * TL_PIECE;
+            const unsigned int n = min(a.d_n_neigh[i], cap);
             const size_t head = a.d_head_list[i];
-            for (unsigned int k = lane; k < n; k += 64)
-                a.d_nlist[head + k] = tidx[tile_unslot((unsigned int)trow[((k & ~15u) << 4) | (k & 15u)] & slot_mask)];
+            // Rows laid out by type hold up to three entries of the dummy candidate between their two parts: the n listed
+            // neighbors are the first n entries that are not the dummy (what follows them is padding or stale).
+            const unsigned int dummy = tile_slot(T.off[64]);
+            unsigned int out = 0;
+            for (unsigned int k0 = 0; k0 < min(n + 3u, cap) && out < n; k0 += 64)
+                {
+                const unsigned int k = k0 + lane;
+                unsigned int slot = dummy;
+                if (k < min(n + 3u, cap))
+                    slot = (unsigned int)trow[((k & ~15u) << 4) | (k & 15u)] & slot_mask;
+                const bool real = slot != dummy;
+                const unsigned long long m = __ballot(real);
+                const unsigned int pos = out + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+                if (real && pos < n)
+                    a.d_nlist[head + pos] = tidx[tile_unslot(slot)];
+                out += (unsigned int)__popcll(m);
+                }
             }
         hfirst += n_cell;
         }

@@ -310,7 +310,9 @@ __device__ __forceinline__ pft_axis pft_axis_cell(int c, int dim, bool periodic)
 // read, and to a second slot-ordered buffer (st.d_cpos must not be g.d_cpos: other workgroups are still staging from it).
 // WAVES: 4, or 8 for regions so large that only two workgroups fit the LDS of a CU -- the same sixteen waves per CU then
 // (the waves of the second half take the upper two layers of the region in the staging phase).
-template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false, bool STEP = false, int WAVES = PFT_WAVES>
+// BY_TYPE (two types): the rows are laid out by type (hmd_tile_geom_t::rows_by_type), every chunk of four entries has one
+// type and its first entry tells which -- cutoff and parameters are chosen once per chunk, not once per pair.
+template<class Ev, unsigned int SHIFT, bool VIRIAL, bool SINGLE_TYPE, bool TWO_TYPES = false, bool STEP = false, int WAVES = PFT_WAVES, bool BY_TYPE = false>
 __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 registers): what the LDS tile allows anyway
     pair_force_tiles_kernel(hmd_pair_args_t a, hmd_tile_geom_t g, const unsigned short* d_tile_nlist, const typename Ev::param_type* d_params,
                             pft_launch_t lp, pft_step_t st)
@@ -711,7 +713,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
                         }
                     else
                         {
-                        const bool second = c.t[m % (SINGLE_TYPE ? 1 : 4)] != 0u;
+                        const bool second = c.t[(BY_TYPE ? 0 : m) % (SINGLE_TYPE ? 1 : 4)] != 0u;
                         rc[m] = second ? rc2[1] : rc2[0];
                         pp[m] = second ? &prm2[1] : &prm2[0];
                         }
@@ -940,6 +942,8 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
     // Eight waves per workgroup where the region is so large that only two workgroups fit the LDS of a CU (densely
     // filled cells): the CU then holds sixteen waves as it does with four workgroups of four.  (The kernel with the
     // integration pass riding on it exists with four waves only.)
+    // (A/B switch: the kernel with per-pair parameter selects also on rows laid out by type)
+    const bool by_type = g.rows_by_type && !std::getenv("HOOMD_AMD_PFT_NO_BY_TYPE");
     bool eight = !STEP && 3 * (lds + 1024) > 160 * 1024;
     if (const char* w = std::getenv("HOOMD_AMD_PFT_WAVES"))
         eight = !STEP && std::atoi(w) == 8;
@@ -969,8 +973,23 @@ int pft_launch2(const hmd_pair_args_t& a, const hmd_tile_geom_t& g, const unsign
         if constexpr (!STEP)
             if (eight)
                 {
+                if constexpr (SHIFT == 0 && !VIRIAL && has_branch_free4<Ev>::value)
+                    if (by_type)
+                        {
+                        tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8, true>, lds);
+                        hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
+                        return hmd_launch_status();
+                        }
                 tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8>, lds);
                 hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 8>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
+                return hmd_launch_status();
+                }
+        // rows laid out by type: the kernel that picks parameters per chunk (the plain potential without virials)
+        if constexpr (!STEP && SHIFT == 0 && !VIRIAL && has_branch_free4<Ev>::value)
+            if (by_type)
+                {
+                tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 4, true>, lds);
+                hipLaunchKernelGGL((pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, false, 4, true>), grid, block, lds, s, a, g, d_tile_nlist, d_params, lp, st);
                 return hmd_launch_status();
                 }
         tile_allow_big_lds(pair_force_tiles_kernel<Ev, SHIFT, VIRIAL, false, true, STEP>, lds);

@@ -255,7 +255,7 @@ class FusedStepArgs(C.Structure):
 
 class TileGeom(C.Structure):
     _fields_ = [("d_cell_size", vp), ("d_cell_idx", vp), ("ci", Index3D), ("cli", Index2D), ("capacity", u32), ("d_cpos", vp),
-                ("d_slot_meta", vp), ("d_block_group", vp), ("row_pieces", u32)]
+                ("d_slot_meta", vp), ("d_block_group", vp), ("row_pieces", u32), ("rows_by_type", u32)]
 
 
 class NlistTilesArgs(C.Structure):
@@ -336,6 +336,7 @@ _SIGNATURES = {
     "hmd_tile_refresh": (C.c_int, [vp, vp, vp, u32, vp]),
     "hmd_compute_nlist_tiles": (C.c_int, [C.POINTER(NlistTilesArgs), vp]),
     "hmd_nlist_tiles_to_rows": (C.c_int, [C.POINTER(TilesToRowsArgs), vp]),
+    "hmd_nlist_tiles_rows_by_type": (C.c_int, [C.POINTER(NlistTilesArgs)]),
     "hmd_compute_pair_forces_lj_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
     "hmd_compute_pair_forces_example_tiles": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, vp]),
     "hmd_compute_pair_forces_lj_tiles_step": (C.c_int, [C.POINTER(PairArgs), C.POINTER(TileGeom), vp, vp, C.POINTER(FusedStepArgs), vp]),

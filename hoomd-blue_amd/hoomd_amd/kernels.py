@@ -213,9 +213,10 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None, exclusions=N
     geom.d_block_group = ptr(block_group)
     while True:
         head, total = build_head_list(pos, N, Nmax_t)
-        geom.row_pieces = (int(Nmax_t.max().item()) + 15) // 16
+        geom.row_pieces = (int(Nmax_t.max().item()) + (3 if nt == 2 else 0) + 15) // 16  # (rows by type: up to three dummy entries)
         entries = _abi.lib.hmd_nlist_tiles_storage_entries(C.byref(geom.ci), n_members, geom.row_pieces)
-        tiles = torch.zeros(entries, dtype=torch.int16, device=dev)
+        # (not zeros: an entry the build should have written and did not must show -- 5 is the slot of a real candidate)
+        tiles = torch.full((entries,), 5, dtype=torch.int16, device=dev)
         overflow.zero_()
         n_neigh = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
         cond = torch.zeros(nt, dtype=torch.int32, device=dev)
@@ -233,6 +234,8 @@ def nlist_tiles(pos, N, box, r_cut, r_buff, cl, adj, capacity=None, exclusions=N
             a.d_n_ex_idx, a.d_ex_list_idx = ptr(exclusions[0]), ptr(exclusions[1])
             a.exli = Index2D(exclusions[1].shape[1], exclusions[1].shape[0])
         check(_abi.lib.hmd_compute_nlist_tiles(C.byref(a), _stream(pos)), "hmd_compute_nlist_tiles")
+        # (two types: rows laid out by type; the force entry points read this from the geometry)
+        geom.rows_by_type = a.geom.rows_by_type = int(_abi.lib.hmd_nlist_tiles_rows_by_type(C.byref(a)))
         n_builds += 1
         if int(overflow[0].item()):
             raise _abi.KernelError("tile capacity exceeded")

@@ -1269,7 +1269,8 @@ class NeighborListGPUBinned : public Compute
     DeviceArray<unsigned int> m_slot_of;   // particle index -> cell-list slot
     DeviceArray<Scalar4> m_cpos;           // positions in slot order, refreshed before each force launch
     DeviceArray<Scalar4> m_cpos_alt;       // where a pass riding on the force kernel puts the next step's positions
-    DeviceArray<hmd_uint4> m_slot_meta;    // per slot: particle index, n_neigh, row offset / 4
+    DeviceArray<hmd_uint4> m_slot_meta;    // per slot: particle index, entries of the row
+    bool m_rows_by_type = false;           // the rows of the last build are laid out by type (two types)
 
     // exclusions
     bool m_exclusions_set = false, m_ex_dirty = false;

@@ -540,7 +540,8 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         // member of the cell list (owned and ghost) plus one partly filled group per block
         const hmd_index3d_t ci = m_cl->getCellIndexer();
         const unsigned int nmax_all = *std::max_element(m_Nmax.begin(), m_Nmax.end());
-        m_row_pieces = (nmax_all + 15) / 16;
+        // (with two types the rows are laid out by type and hold up to three entries of the dummy candidate besides the neighbors)
+        m_row_pieces = (nmax_all + (m_pdata->getNTypes() == 2 ? 3u : 0u) + 15) / 16;
         const size_t entries = hmd_nlist_tiles_storage_entries(&ci, m_pdata->getN() + m_pdata->getNGhosts(), m_row_pieces);
         if (m_tile_nlist.size() < entries)
             m_tile_nlist.resize(entries + entries / 8, false);
@@ -580,6 +581,7 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
         a.ntypes = m_pdata->getNTypes();
         a.d_tile_overflow = m_conditions.get() + a.ntypes;
         a.tile_nlist_entries = m_tile_nlist.size();
+        m_rows_by_type = hmd_nlist_tiles_rows_by_type(&a) != 0; // (the force launches that read these rows are told)
         if (m_exclusions_set)
             {
             // left out while the rows are written: no filter pass over tile rows (hoomd/md/NeighborListGPU.cu:158-223)
@@ -643,6 +645,7 @@ hmd_tile_geom_t NeighborListGPUBinned::getTileGeom() const
     g.d_slot_meta = m_slot_meta.get();
     g.d_block_group = m_block_group.get();
     g.row_pieces = m_row_pieces;
+    g.rows_by_type = m_rows_by_type ? 1u : 0u;
     return g;
     }
 

@@ -922,6 +922,10 @@ typedef struct
        hmd_compute_nlist_tiles) and the number of 16-entry pieces every row has room for. */
     const unsigned int* d_block_group;
     unsigned int row_pieces;
+    /* 1 when the rows were laid out by type (two particle types: the neighbors of type 0, the dummy candidate up to a
+       multiple of four entries, then the neighbors of type 1), as hmd_nlist_tiles_rows_by_type says of the build that
+       wrote them; the pair-force entry points then choose parameters per chunk of four entries.  0 is always valid. */
+    unsigned int rows_by_type;
     } hmd_tile_geom_t;
 
 /* Number of 16-bit entries d_tile_nlist must hold for a cell grid whose cells hold n_members particles in all
@@ -992,6 +996,11 @@ typedef struct
                                         candidate's type in the top three bits of an entry, the slot in the low 13 */
     } hmd_tiles_to_rows_args_t;
 int hmd_nlist_tiles_to_rows(const hmd_tiles_to_rows_args_t* args, void* stream);
+/* Whether hmd_compute_nlist_tiles lays the rows of this build out by type (see hmd_tile_geom_t::rows_by_type): two
+ * types, no body filter, orthorhombic box, at least three cells along every periodic direction.  No counterpart in the
+ * reference, whose rows are in cell-walk order (hoomd/md/NeighborListGPUBinned.cu:168-287); the order within a row is
+ * free there too. */
+int hmd_nlist_tiles_rows_by_type(const hmd_nlist_tiles_args_t* args);
 
 /* Pair forces from tile rows; args->d_nlist, d_head_list and size_neigh_list are ignored (geom locates the rows),
    threads_per_particle must be 0 or 4 (four lanes share a home particle), everything else as

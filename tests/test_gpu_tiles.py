@@ -209,6 +209,54 @@ def test_tile_forces_with_densely_filled_cells(K, A, ntypes):
     assert _rel_err(F2.cpu().numpy(), F_ref) < tol
 
 
+@pytest.mark.parametrize("jitter", [0.0, 0.05])
+def test_tile_rows_laid_out_by_type(K, A, jitter, monkeypatch):
+    """Two types: the build lays a row out as [type 0 ..., dummy up to a multiple of four, type 1 ...] and the force kernel
+    chooses its parameters per chunk of four entries.  An 80:20 mixture at density 1.2 with three cutoffs, on the lattice
+    (every row of a type as long as the longest: the rows end exactly at their capacity; 37 particles per cell: more
+    candidates than one pass of the build holds, so it sweeps once per type) and off it: neighbor sets and counts are the
+    oracle's, the capacities too (the dummy entries do not count), forces to 1e-10 of the largest with either kernel."""
+    n, rho = 20, 1.2
+    a = (1.0 / rho) ** (1.0 / 3.0)
+    L = n * a
+    g = (np.arange(n) + 0.5) * a - L / 2
+    xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    if jitter:
+        xyz = xyz + rng.normal(0, jitter, xyz.shape)
+    xyz = (xyz + L / 2) % L - L / 2
+    typ = (rng.random(len(xyz)) < 0.2).astype(int)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos = orc.pack_pos(xyz, typ)
+    r_cut = [[2.5, 2.0], [2.0, 2.2]]
+    P = [orc.lj_params(1.0, 1.0), orc.lj_params(0.8, 1.5), orc.lj_params(0.8, 1.5), orc.lj_params(0.88, 0.5)]
+    pos_t = torch.from_numpy(pos).cuda()
+    tl, cl, _ = tile_nlist(K, A, pos_t, N, gbox, obox, r_cut, 0.4)
+    assert tl["geom"].rows_by_type == 1
+    assert 27 * cl["cell_size"].cpu().numpy().max() > 14 * 64  # (more than one pass)
+    ref = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=True)
+    assert np.array_equal(tl["n_neigh"].cpu().numpy().view(np.uint32)[:N], ref["n_neigh"])
+    assert np.array_equal(tl["Nmax"].cpu().numpy().view(np.uint32), ref["Nmax"])
+    sets = expanded_sets(K, tl, N, gbox)
+    rsets = orc.neighbor_sets(ref["n_neigh"], ref["nlist"], ref["head"])
+    assert all(np.array_equal(s, r) for s, r in zip(sets, rsets))
+    # what the rows hold: per home particle the entries counted in the slot table = listed neighbors + the dummy entries
+    lay = tl["slot_meta"].cpu().numpy().view(np.uint32)[tl["slot_of"].cpu().numpy()[:N], 1]
+    extra = lay.astype(np.int64) - ref["n_neigh"]
+    assert extra.min() >= 0 and extra.max() <= 3 and extra.max() > 0
+    half = orc.nlist_binned(pos, N, obox, r_cut, 0.4, storage_full=False)
+    rcutsq = np.square(r_cut)
+    F_ref, _ = orc.pair_forces(orc.EV_LJ, pos, N, obox, half["n_neigh"], half["nlist"], half["head"], P, rcutsq, np.zeros_like(rcutsq),
+                               shift_mode=0, third_law=True, compute_virial=False)
+    scale = np.abs(F_ref).max()
+    for per_pair in (False, True):
+        if per_pair:
+            monkeypatch.setenv("HOOMD_AMD_PFT_NO_BY_TYPE", "1")  # the kernel that reads the type of every entry
+        F, _ = K.pair_forces_tiles("lj", pos_t, N, gbox, tl, P, rcutsq, np.zeros_like(rcutsq), shift_mode=0, compute_virial=False)
+        assert np.abs(F.cpu().numpy() - F_ref).max() < 1e-10 * scale
+
+
 def test_tile_path_limits_are_reported(K, A):
     gbox, _ = boxes(A, 5.0)
     xyz = (np.random.default_rng(1).random((50, 3)) - 0.5) * 5.0
