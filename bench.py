@@ -188,9 +188,10 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
+    # (defaults: the protocol of the measurement plan -- 10,000 steps of equilibration, 2,000 of warm-up, 5,000 timed)
+    ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--equil", type=int, default=2000,
+    ap.add_argument("--equil", type=int, default=10000,
                     help="untimed equilibration steps before the warm-up: the lattice melts under the thermostat, the last 200 are NVE")
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
                     help="weak: --lattice sites PER GPU (default 128x128x64, N = 2^20 per GPU); strong: --lattice sites IN ALL "
@@ -201,7 +202,7 @@ def main():
     ap.add_argument("--tpp", type=int, default=0)
     ap.add_argument("--workload", type=str, default="lj", choices=["lj", "ka", "kg"],
                     help="lj: the headline LJ liquid; side measurements: ka = Kob-Andersen 80:20 mixture at rho 1.2 under a Bussi "
-                         "thermostat, kg = Kremer-Grest bead-spring melt (WCA + FENE bonds, chains of 32 along the lattice's x rows)")
+                         "thermostat, kg = Kremer-Grest bead-spring melt (WCA + FENE bonds, chains of 64 along the lattice's x rows at rho = 0.85)")
     ap.add_argument("--time-all", action="store_true", help="time every kernel family with HIP events (perturbs the run) and print the table to stderr")
     ap.add_argument("--time-every", type=int, default=4,
                     help="bracket one pair-force launch in this many with HIP events for the roofline (1: every launch)")
@@ -276,7 +277,9 @@ def main():
         sim, cell, lj, method = lj_liquid.make_ka_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
     elif args.workload == "kg":
         thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.0, tau=0.5)
-        sim, cell, lj, fene, method = lj_liquid.make_kg_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
+        # chains of 64 at rho = 0.85 (0.97 along the chains, 1.1013 across them on the start lattice)
+        sim, cell, lj, fene, method = lj_liquid.make_kg_simulation(hoomd, n, chain_length=64, across=(1.0 / (0.85 * 0.97)) ** 0.5, thermostat=thermostat,
+                                                                   decomposition=decomposition)
     else:
         thermostat = hoomd.md.methods.thermostats.Berendsen(kT=1.5, tau=0.5)
         sim, cell, lj, method = lj_liquid.make_simulation(hoomd, n, thermostat=thermostat, decomposition=decomposition)
@@ -419,7 +422,7 @@ def main():
                 "workload": (f"Kob-Andersen 80:20 LJ mixture N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) "
                              "rho=1.2 kT=1.0 r_cut=2.5 sigma_ij buffer=0.4 dt=0.005, Cell nlist + LJ + ConstantVolume with Bussi thermostat, fp64"
                              if args.workload == "ka" else
-                             f"Kremer-Grest melt N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, chains of 32) rho=0.935 kT=1.0 WCA r_cut=2^(1/6) shifted + "
+                             f"Kremer-Grest melt N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, chains of 64) rho=0.85 kT=1.0 WCA r_cut=2^(1/6) shifted + "
                              "FENE k=30 r0=1.5, bond exclusions, buffer=0.4 dt=0.005, Cell nlist + ConstantVolume (NVE), fp64"
                              if args.workload == "kg" else
                              f"LJ liquid N={N_total} ({n[0]}x{n[1]}x{n[2]} lattice, {per_gpu[0]}x{per_gpu[1]}x{per_gpu[2]} per GPU) rho=0.84 kT=1.5 "

@@ -71,15 +71,15 @@ def make_ka_simulation(hoomd, n, rho=1.2, kT=1.0, buffer=0.4, dt=0.005, seed=123
     return sim, cell, lj, method
 
 
-def make_kg_snapshot(hoomd, n, chain_length=32, kT=1.0, seed=1234, jitter=0.02):
+def make_kg_snapshot(hoomd, n, chain_length=32, kT=1.0, seed=1234, jitter=0.02, across=1.05):
     """Kremer-Grest melt start: linear chains laid along x on an n[0] x n[1] x n[2] lattice (spacing 0.97 along the
-    chains, 1.05 across them: rho = 0.935), every chain_length consecutive sites of a row bonded (rows wrap around
-    the periodic box, so n[0] must be a multiple of chain_length)."""
+    chains, `across` between them: 1.05 gives rho = 0.935, 1.1013 rho = 0.85), every chain_length consecutive sites of
+    a row bonded (rows wrap around the periodic box, so n[0] must be a multiple of chain_length)."""
     if isinstance(n, int):
         n = (n, n, n)
     if n[0] % chain_length:
         raise ValueError("n[0] must be a multiple of chain_length")
-    a = np.array([0.97, 1.05, 1.05])
+    a = np.array([0.97, across, across])
     L = np.array(n) * a
     rng = np.random.default_rng(seed)
     g = [(np.arange(k) + 0.5) * s - l / 2 for k, s, l in zip(n, a, L)]
@@ -102,10 +102,11 @@ def make_kg_snapshot(hoomd, n, chain_length=32, kT=1.0, seed=1234, jitter=0.02):
     return snap
 
 
-def make_kg_simulation(hoomd, n, chain_length=32, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200, decomposition=None):
+def make_kg_simulation(hoomd, n, chain_length=32, kT=1.0, buffer=0.4, dt=0.005, seed=1234, thermostat=None, sorter_period=200, decomposition=None,
+                       across=1.05):
     """WCA pair force (LJ cut at 2^(1/6), shifted) + FENE/WCA bonds (k = 30, r0 = 1.5), bonded pairs excluded from
     the pair force: the Kremer-Grest bead-spring melt."""
-    snap = make_kg_snapshot(hoomd, n, chain_length, kT, seed)
+    snap = make_kg_snapshot(hoomd, n, chain_length, kT, seed, across=across)
     sim = hoomd.Simulation(device=hoomd.device.GPU(), seed=seed)
     if decomposition is not None:
         sim.create_state_from_snapshot(snap, domain_decomposition=decomposition)

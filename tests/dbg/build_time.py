@@ -58,3 +58,21 @@ for i in range(40):
     ev[i + 1].record()
 torch.cuda.synchronize()
 print("per launch us", [round(ev[i].elapsed_time(ev[i + 1]) * 1e3) for i in range(40)])
+# a long series (BUILD_SERIES launches, back to back): does the duration drift or jump once the device has been busy for seconds?
+n_series = int(os.environ.get("BUILD_SERIES", "0"))
+if n_series:
+    import subprocess
+    chunk = 200
+    for c0 in range(0, n_series, chunk):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(chunk + 1)]
+        ev[0].record()
+        for i in range(chunk):
+            A.check(A.lib.hmd_compute_nlist_tiles(C.byref(tl["args"]), None))
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        d = np.array([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(chunk)])
+        print("launches %5d..%5d  median %4.0f  mean %4.0f  max %4.0f  above 470 us: %3d" % (c0, c0 + chunk, np.median(d), d.mean(), d.max(), (d > 470).sum()), flush=True)
+    try:
+        print(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=20).stdout[-1500:])
+    except Exception as e:
+        print("rocm-smi:", e)
