@@ -757,10 +757,8 @@ void CommunicatorGPU::exchangeGhosts(Scalar r_ghost)
     m_prev_send_rows = m_send_rows;
     m_prev_recv_rows = m_recv_rows;
     m_have_prev_rows = true;
-    const unsigned int n_ghost = m_pdata->getNGhosts();
     buildVotePlan();
-    hipCheck(hipMemsetAsync(m_pdata->rtag(), 0xff, sizeof(unsigned int) * std::max(m_pdata->getNGlobal(), 1u), nullptr), "clear rtag");
-    abiCheck(hmd_build_rtag(m_pdata->rtag(), m_pdata->tag(), N + n_ghost, nullptr), "hmd_build_rtag");
+    m_pdata->markRtagStale(); // whoever reads the tag -> index table next (bond table, exclusions, snapshots) rebuilds it
     }
 
 // Row maps for the halo exchange that also carries the rebuild vote: every message gets one extra row.  Only when this

@@ -342,9 +342,19 @@ class ParticleData
         {
         return m_tag.get();
         }
+    //! index of every tag (local particles and ghosts; 0xffffffff for tags this rank does not hold); brought up to date
+    //! here when an exchange has left it stale (markRtagStale)
     unsigned int* rtag() const
         {
+        if (m_rtag_stale)
+            refreshRtag();
         return m_rtag.get();
+        }
+    //! the set of local particles and ghosts has changed (migration, new ghost layer): the next reader of rtag()
+    //! rebuilds it -- runs without bonds, exclusions or snapshots never pay for the two launches
+    void markRtagStale()
+        {
+        m_rtag_stale = true;
         }
     unsigned int* body() const
         {
@@ -528,6 +538,8 @@ class ParticleData
     DeviceArray<Scalar3> m_accel, m_alt3;
     DeviceArray<int3> m_image, m_alti3;
     DeviceArray<unsigned int> m_tag, m_rtag, m_body, m_altu;
+    mutable bool m_rtag_stale = false;
+    void refreshRtag() const;
     DeviceArray<Scalar> m_charge, m_diameter, m_net_virial, m_alt1;
     Scalar4* m_net_force_alias = nullptr;
     DisplacementCheckHook m_check_hook;

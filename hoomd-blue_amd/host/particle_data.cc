@@ -301,6 +301,7 @@ void ParticleData::initializeFromSnapshot(const SnapshotParticleData& snap)
     m_image.upload(image.data(), n);
     m_tag.upload(tag.data(), n);
     abiCheck(hmd_build_rtag(m_rtag.get(), m_tag.get(), n, nullptr), "build rtag");
+    m_rtag_stale = false;
     m_body.upload(body.data(), n);
     m_charge.upload(charge.data(), n);
     m_diameter.upload(diameter.data(), n);
@@ -374,8 +375,16 @@ void ParticleData::applyOrder(const unsigned int* d_order)
     m_charge.swap(m_alt1);
     abiCheck(hmd_gather_rows(m_alt1.get(), m_diameter.get(), d_order, n, 8, nullptr), "gather diameter");
     m_diameter.swap(m_alt1);
-    abiCheck(hmd_build_rtag(m_rtag.get(), m_tag.get(), n, nullptr), "build rtag");
+    if (!m_rtag_stale) // (a stale table is rebuilt whole by its next reader)
+        abiCheck(hmd_build_rtag(m_rtag.get(), m_tag.get(), n, nullptr), "build rtag");
     notifyParticleSort();
+    }
+
+void ParticleData::refreshRtag() const
+    {
+    hipCheck(hipMemsetAsync(m_rtag.get(), 0xff, sizeof(unsigned int) * m_rtag.size(), nullptr), "clear rtag");
+    abiCheck(hmd_build_rtag(m_rtag.get(), m_tag.get(), m_N + m_nghost, nullptr), "build rtag");
+    m_rtag_stale = false;
     }
 
 // ---------------------------------------------------------------------------------------------
