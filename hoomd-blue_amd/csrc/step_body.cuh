@@ -17,6 +17,15 @@ __device__ __forceinline__ bool hmd_fused_step_particle(const hmd_fused_step_arg
 #pragma clang fp contract(off)
     const double4 v = hmd_ld4(a.one.d_vel + idx);
     const double4 p = hmd_ld4(a.one.d_pos + idx);
+    // (everything the pass reads is asked for here, ahead of the stores: the compiler may not move a load across a store
+    // through another pointer, and read where they are used the position of the last build and the slot cost every wave a
+    // second round trip to memory)
+    double4 last = make_double4(0, 0, 0, 0);
+    if (check)
+        last = hmd_ld4(a.check.d_last_pos + idx);
+    unsigned int slot = 0;
+    if (a.d_cpos)
+        slot = a.d_slot_of[idx];
     hmd_scalar3 acc;
     double vx = v.x, vy = v.y, vz = v.z;
     if (STEP_TWO)
@@ -57,12 +66,11 @@ __device__ __forceinline__ bool hmd_fused_step_particle(const hmd_fused_step_arg
         a.one.d_image[idx] = img;
         }
     if (a.d_cpos)
-        hmd_st4(a.d_cpos + a.d_slot_of[idx], x, y, z, p.w);
+        hmd_st4(a.d_cpos + slot, x, y, z, p.w);
     // ---- distance check of the new position (hoomd/md/NeighborListGPU.cu:42-84) ----
     bool moved = false;
     if (check)
         {
-        const double4 last = hmd_ld4(a.check.d_last_pos + idx);
         double dx = HMD_SUB(x, HMD_MUL(a.check.lambda.x, last.x));
         double dy = HMD_SUB(y, HMD_MUL(a.check.lambda.y, last.y));
         double dz = HMD_SUB(z, HMD_MUL(a.check.lambda.z, last.z));
