@@ -26,6 +26,10 @@ __device__ __forceinline__ bool hmd_fused_step_particle(const hmd_fused_step_arg
     unsigned int slot = 0;
     if (a.d_cpos)
         slot = a.d_slot_of[idx];
+    // (the cutoff of the particle's type likewise: with one type a uniform read, otherwise asked for as soon as the type is known)
+    double rmin = 0.0;
+    if (check)
+        rmin = a.check.d_rcut_max[a.check.ntypes == 1u ? 0u : hmd_double_as_uint(p.w)];
     hmd_scalar3 acc;
     double vx = v.x, vy = v.y, vz = v.z;
     if (STEP_TWO)
@@ -75,7 +79,6 @@ __device__ __forceinline__ bool hmd_fused_step_particle(const hmd_fused_step_arg
         double dy = HMD_SUB(y, HMD_MUL(a.check.lambda.y, last.y));
         double dz = HMD_SUB(z, HMD_MUL(a.check.lambda.z, last.z));
         hmd_min_image<ORTHO>(a.check.box, dx, dy, dz);
-        const double rmin = a.check.d_rcut_max[hmd_double_as_uint(p.w)];
         const double rmax = HMD_ADD(rmin, a.check.r_buff);
         const double delta_max = HMD_SUB(HMD_MUL(rmax, a.check.lambda_min), rmin) / 2.0;
         const double maxsq = (delta_max > 0) ? HMD_MUL(delta_max, delta_max) : 0.0;
