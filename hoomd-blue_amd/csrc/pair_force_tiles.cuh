@@ -430,6 +430,10 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
     // row info of the home cells' members.  The cell sizes arrive in the same round trip (wave 0 below):
     // staging costs one memory latency, not three.
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    // The staging phase runs at raised wave priority: its few instructions (addresses, loads, LDS stores) otherwise queue
+    // behind the arithmetic of the three other workgroups on the compute unit, and a workgroup that is slow to get its
+    // region in place holds a quarter of the unit's LDS and wave slots without computing (pair kernel 125 -> 119 us).
+    __builtin_amdgcn_s_setprio(2);
     static_assert(WAVES == 4 || WAVES == 8, "four or eight waves");
     constexpr int TRIPS = 4 * PFT_WAVES / WAVES;
     const unsigned int rx = lane / 16, k16 = lane % 16;
@@ -610,6 +614,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
         txyz[v + 64] = 1e30;
         }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
 
     // ---- forces: a wave takes the block's groups of sixteen rows in turn (wave w: groups w, w + 4, ...).  The
     // first PFT_PRE pieces of every row of the next group are fetched while the present one is computed: rows
