@@ -563,16 +563,17 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu((
                                                               unsigned int row_pieces, nl_excl_t ex)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
+    const unsigned int nwaves = blockDim.x >> 6; // waves per workgroup: four, or one (a workgroup per cell)
     unsigned int* s_excl_all = reinterpret_cast<unsigned int*>(s_raw);
-    unsigned int* s_cell_all = s_excl_all + 64 * NL_WAVES;
-    double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * NL_WAVES);
-    unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * NL_WAVES);
-    unsigned int* s_rowbuf = s_tileoff_all + 64 * NL_WAVES;
+    unsigned int* s_cell_all = s_excl_all + 64 * nwaves;
+    double* s_shift_all = reinterpret_cast<double*>(s_cell_all + 64 * nwaves);
+    unsigned int* s_tileoff_all = reinterpret_cast<unsigned int*>(s_shift_all + 3 * 64 * nwaves);
+    unsigned int* s_rowbuf = s_tileoff_all + 64 * nwaves;
     // which adjacent cell a candidate belongs to, without a search: a byte per candidate number that is set where a
     // (non-empty) cell starts, and the non-empty cells in order
-    unsigned int* s_map_all = s_rowbuf + NL_ROWBUF * NL_WAVES;
+    unsigned int* s_map_all = s_rowbuf + NL_ROWBUF * nwaves;
     const unsigned int flag_bytes = nl_pref_flag_bytes(a.cli.w);
-    unsigned char* s_flag_all = reinterpret_cast<unsigned char*>(s_map_all + 32 * NL_WAVES);
+    unsigned char* s_flag_all = reinterpret_cast<unsigned char*>(s_map_all + 32 * nwaves);
 
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(NL_BLOCK) __attribute__((amdgpu_waves_per_eu((
             band_f_bits = __float_as_uint((pf0.hi - pf0.lo) * 1.001f + 1.0e-30f);
         }
 
-    const unsigned int cells_per_block = NL_WAVES / wpc;
+    const unsigned int cells_per_block = nwaves / wpc;
     const unsigned int vb = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned int cell = vb * cells_per_block + wave / wpc;
     const unsigned int sub = wave % wpc;
@@ -1385,7 +1386,7 @@ __global__ void __launch_bounds__(NL_BLOCK) nlist_block_kernel(hmd_nlist_binned_
     const unsigned int lo1 = pf.hi > 0.0f ? __float_as_uint(pf.lo) + 1u : 0u;
     const unsigned int band = pf.hi > 0.0f ? __float_as_uint(pf.hi) - __float_as_uint(pf.lo) : 0u;
 
-    const unsigned int tb = xcd_remap(blockIdx.x, gridDim.x) * NL_WAVES + wave;
+    const unsigned int tb = xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave; // (one wave per workgroup, or four)
     if (tb >= nblocks)
         return;
     const int dim[3] = {(int)a.ci.w, (int)a.ci.h, (int)a.ci.d};
@@ -2070,6 +2071,18 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
         }
     }
 
+// threads per workgroup of the build kernels whose waves work on their own: 64, or HOOMD_AMD_NL_BLOCK (64, 128 or 256)
+static unsigned int nl_wave_block()
+    {
+    if (const char* e = std::getenv("HOOMD_AMD_NL_BLOCK"))
+        {
+        const int v = std::atoi(e);
+        if (v == 64 || v == 128 || v == 256)
+            return (unsigned int)v;
+        }
+    return 64u;
+    }
+
 template<bool ST, bool FB>
 int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned int wpc, size_t lds, hipStream_t s, unsigned short* d_tile = nullptr,
                  unsigned int tile_capacity = 0, unsigned int* d_tile_overflow = nullptr, hmd_uint4* d_slot_meta = nullptr,
@@ -2096,10 +2109,14 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
         // (fp32 coordinates are relative to a point of the 4x4x4-cell region: up to four cell widths away, not two)
         wmax *= 2.0;
         const unsigned int nblk = hmd::tile_num_blocks(a.ci);
-        const dim3 bgrid(hmd_div_up(nblk, NL_WAVES));
-        const size_t lds_blk = sizeof(unsigned int) * (64 + 64 + 6 * 64 + 8 * 64 + NL_ROWBUF) * NL_WAVES;
+        // One wave per workgroup: the waves share nothing, and the wave slots and the LDS of a finished block are free at
+        // once instead of when the slowest of four is done (Kremer-Grest step 0.378 -> 0.371 ms).  HOOMD_AMD_NL_BLOCK=256
+        // brings the four-wave workgroups back (A/B).
+        const unsigned int blk_block = nl_wave_block();
+        const dim3 bgrid(hmd_div_up(nblk, blk_block / 64u));
+        const size_t lds_blk = sizeof(unsigned int) * (64 + 64 + 6 * 64 + 8 * 64 + NL_ROWBUF) * (blk_block / 64u);
 #define HMD_BLOCK_LAUNCH(TILE_, EXCL_, ...) \
-    hipLaunchKernelGGL((nlist_block_kernel<TILE_, EXCL_, 12>), bgrid, dim3(NL_BLOCK), lds_blk, s, a, nblk, wmax, __VA_ARGS__)
+    hipLaunchKernelGGL((nlist_block_kernel<TILE_, EXCL_, 12>), bgrid, dim3(blk_block), lds_blk, s, a, nblk, wmax, __VA_ARGS__)
         if (d_tile && ex.d_n_ex)
             HMD_BLOCK_LAUNCH(true, true, d_tile, tile_capacity, d_tile_overflow, d_slot_meta, d_slot_of, d_cpos, d_block_group, row_pieces, ex);
         else if (d_tile)
@@ -2118,7 +2135,12 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
         const double gw[3] = {a.ghost_width.x, a.ghost_width.y, a.ghost_width.z};
         for (int d = 0; d < 3; d++)
             wmax = std::max(wmax, (a.box.L[d] + 2.0 * gw[d]) / (double)dim[d]);
-        const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF + 32) + sizeof(double) * 3 * 64 + nl_pref_flag_bytes(a.cli.w)) * NL_WAVES;
+        // A workgroup per cell (one wave) where a cell has one wave: the waves share nothing, and the wave slots and the LDS
+        // of a finished cell are free at once, not when the slowest of four cells is done (build 423 -> 408 us on the LJ
+        // liquid, Kob-Andersen step 1.365 -> 1.337 ms)
+        const unsigned int pref_block = wpc == 1 ? nl_wave_block() : NL_BLOCK;
+        const dim3 grid(hmd_div_up(ncells, (pref_block / 64u) / wpc));
+        const size_t lds_pref = (sizeof(unsigned int) * (192 + NL_ROWBUF + 32) + sizeof(double) * 3 * 64 + nl_pref_flag_bytes(a.cli.w)) * (pref_block / 64u);
 // candidates in registers: 12 slabs of 64 cover the 27 cells of liquids up to 28 particles per cell in one pass (the
 // LJ liquid has 21.5); denser systems (the binary mixture at density 1.2: 29) get 14 slabs, at three waves per SIMD
 // instead of four, rather than a second pass over a handful of candidates.  Decided by the mean occupancy.
@@ -2127,9 +2149,9 @@ int launch_nlist(const hmd_nlist_binned_args_t& a, unsigned int ncells, unsigned
     do                                                                                                                                             \
         {                                                                                                                                          \
         if (dense)                                                                                                                                 \
-            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 14>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
+            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 14>), grid, dim3(pref_block), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
         else                                                                                                                                       \
-            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 12>), grid, dim3(NL_BLOCK), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
+            hipLaunchKernelGGL((nlist_pref_kernel<TILE_, EXCL_, TWO_, 12>), grid, dim3(pref_block), lds_pref, s, a, ncells, wpc, wmax, __VA_ARGS__); \
         } while (0)
         const bool two = !ST;
         if (d_tile && ex.d_n_ex)
