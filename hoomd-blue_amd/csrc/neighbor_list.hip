@@ -2066,8 +2066,9 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
     if (threadIdx.x == 0)
         {
         d_block_group[nb] = total;
-        if (total > tile_groups)
-            d_tile_overflow[0] = 1u;
+        // the two words of the build that follows start from zero here (a launch less than a memset of their own)
+        d_tile_overflow[0] = total > tile_groups ? 1u : 0u;
+        d_tile_overflow[1] = 0u;
         }
     }
 
@@ -2299,7 +2300,7 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     HMD_REQUIRE(groups_fit > hmd::TL_SLACK_GROUPS && groups_fit - hmd::TL_SLACK_GROUPS <= 0xffffffffull, HMD_ERR_INVALID_ARGUMENT,
                 "hmd_compute_nlist_tiles: tile_nlist_entries holds no group of rows (size it with hmd_nlist_tiles_storage_entries)");
     const unsigned int tile_groups = (unsigned int)(groups_fit - hmd::TL_SLACK_GROUPS);
-    // the caller clears d_tile_overflow; the groups are numbered first, and the build gives up when they do not fit
+    // the groups are numbered first (that kernel also clears d_tile_overflow), and the build gives up when they do not fit
     const size_t bg_lds = (size_t)hmd::tile_num_blocks(t.geom.ci) * sizeof(unsigned int);
     const bool bg_cached = bg_lds <= 60 * 1024;
     hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), bg_cached ? bg_lds : 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci,

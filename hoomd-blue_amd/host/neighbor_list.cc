@@ -589,7 +589,6 @@ void NeighborListGPUBinned::buildNlist(uint64_t timestep)
             a.d_ex_list_idx = m_ex_list_idx.get();
             a.exli = hmd_index2d_t {std::max(m_pdata->getMaxN(), 1u), m_ex_height};
             }
-        hipCheck(hipMemsetAsync(a.d_tile_overflow, 0, 2 * sizeof(unsigned int), 0), "clear tile words");
         abiCheck(hmd_compute_nlist_tiles(&a, nullptr), "hmd_compute_nlist_tiles");
         m_cpos_tstep = timestep; // current for every particle, ghosts included
         m_cpos_all_tstep = timestep;

@@ -967,7 +967,7 @@ typedef struct
     const double* d_r_cut;           /* ntypes x ntypes */
     double r_buff;
     unsigned int ntypes;
-    unsigned int* d_tile_overflow;   /* two words: [0] set to 1 when a region exceeds geom.capacity or the rows
+    unsigned int* d_tile_overflow;   /* two words, cleared by the call: [0] set to 1 when a region exceeds geom.capacity or the rows
                                         need more room than tile_nlist_entries (rows are then invalid); [1] raised
                                         (atomicMax) to the largest region population, the capacity later calls on
                                         these rows need */
