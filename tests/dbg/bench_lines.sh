@@ -1,6 +1,8 @@
+#!/bin/bash
+# The bench lines profiles/ keeps for a tree: tests/dbg/bench_lines.sh <tag>  ->  gpurun_out/<tag>_lines/*.json
 set -e
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03g_lines; mkdir -p $O
+O=gpurun_out/${1:-lines}_lines; mkdir -p $O
 run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > $O/$n.json 2> $O/$n.err; python -c "
 import json,sys; d=json.load(open('$O/$n.json')); print('$n', round(d['ms_per_step'],4), '%.3e'%d['value'], round(d['roofline']['avg_launch_us'],1), round(d['roofline']['frac'],3))"; }
 run bench_default
