@@ -605,10 +605,49 @@ class Communicator:
             import warnings
             warnings.warn(f"RCCL transport not available (rank {bad[0][0]}: {bad[0][1]}); collectives go through torch.distributed")
             return TorchTransport(dd.group, device)
+        # One exchange with unequal messages and one reduction, checked on every rank, before the simulation depends on
+        # the communicator: a transport that does not deliver what was sent is replaced by torch.distributed's, on all
+        # ranks alike.
+        err = Communicator._transport_self_test(transport, dd, device)
+        dist.all_gather_object(oks, err, group=dd.group)
+        bad = [(r, e) for r, e in enumerate(oks) if e is not None]
+        if bad:
+            if want == "rccl":
+                raise RuntimeError(f"RCCL transport: rank {bad[0][0]}: {bad[0][1]}")
+            import warnings
+            warnings.warn(f"RCCL transport failed its self-test (rank {bad[0][0]}: {bad[0][1]}); collectives go through torch.distributed")
+            del transport
+            return TorchTransport(dd.group, device)
         transport.device = device
         transport.stage = False
         transport.side = None
         return transport
+
+    @staticmethod
+    def _transport_self_test(transport, dd, device):
+        """Rank s sends (s + r) % 3 + 1 rows of 32 bytes holding 1000 s + r to rank r and expects the mirror image; then the
+        maximum of the ranks' numbers.  Returns None, or what went wrong."""
+        try:
+            w, me = dd.world, dd.rank
+            send_rows = [(me + r) % 3 + 1 for r in range(w)]
+            out = torch.cat([torch.full((n * 8,), 1000 * me + r, dtype=torch.int32, device=device) for r, n in enumerate(send_rows)])
+            inp = torch.full((sum(send_rows) * 8,), -1, dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            transport.allToAll(out.data_ptr(), send_rows, inp.data_ptr(), send_rows, 32, 0)
+            word = torch.tensor([me], dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            transport.allReduceMaxWord(word.data_ptr(), 0)
+            torch.cuda.synchronize(device)
+            got, off = inp.cpu(), 0
+            for r, n in enumerate(send_rows):
+                if not bool((got[off:off + 8 * n] == 1000 * r + me).all()):
+                    return f"the message of rank {r} arrived as {got[off:off + 8 * n][:4].tolist()}..., expected {1000 * r + me}"
+                off += 8 * n
+            if int(word.item()) != w - 1:
+                return f"the maximum over ranks came out as {int(word.item())}, expected {w - 1}"
+            return None
+        except Exception as e:  # (whatever it is: every rank must reach the gather that follows)
+            return f"{type(e).__name__}: {e}"
 
     def add_nlist(self, nlist):
         self.nlists.append(nlist)

@@ -215,3 +215,41 @@ def test_rccl_transport_issues_send_and_receive_from_cpp():
         t.allToAll(src.data_ptr(), [1, 2], dst.data_ptr(), [1], 4, 0)
     with pytest.raises(ValueError):
         cpp.RcclTransport(b"short", 0, 1)
+
+
+def test_transport_self_test_tells_a_transport_that_delivers_from_one_that_does_not():
+    """Communicator._transport_self_test (run once when the RCCL transport has been set up, before the simulation depends
+    on it): passes for the C++ transport, through RCCL and through its copy path, and names what went wrong for transports
+    that deliver nothing, something else, or raise."""
+    import types
+    import torch
+    from hoomd_amd import _hoomd_amd as cpp
+    from hoomd_amd.comm import Communicator
+    dd = types.SimpleNamespace(world=1, rank=0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = cpp.RcclTransport(cpp.RcclTransport.unique_id(), 0, 1)
+    for through in (False, True):
+        t.self_through_rccl = through
+        assert Communicator._transport_self_test(t, dd, dev) is None
+
+    class Silent:
+        def allToAll(self, *a):
+            pass
+
+        def allReduceMaxWord(self, *a):
+            pass
+
+    class Garbled(Silent):
+        def allToAll(self, d_send, send_rows, d_recv, recv_rows, row_bytes, stream):
+            t.allToAll(d_send, send_rows, d_recv, recv_rows, row_bytes, stream)
+            torch.cuda.synchronize()
+            from hoomd_amd.comm import _DevMem
+            torch.as_tensor(_DevMem(d_recv, (1,), "<i4"), device=dev).fill_(12345)
+
+    class Raising(Silent):
+        def allToAll(self, *a):
+            raise RuntimeError("no route to peer")
+
+    assert "arrived as [-1" in Communicator._transport_self_test(Silent(), dd, dev)
+    assert "arrived as [12345" in Communicator._transport_self_test(Garbled(), dd, dev)
+    assert "no route to peer" in Communicator._transport_self_test(Raising(), dd, dev)
