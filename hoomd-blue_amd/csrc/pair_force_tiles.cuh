@@ -344,6 +344,20 @@ __global__ void __launch_bounds__(64 * WAVES, 4) // four waves per SIMD (128 reg
             return;
             }
         }
+    // (A window launch whose word already says "skip" when a wave first looks ends there as well, before any load: the
+    // word only ever moves towards that value, so no later look can disagree.  Only a word that does not say so yet has
+    // to be read once for the whole workgroup, below.)
+    if (a.d_skip_flag && a.block_window_mode != 0)
+        {
+        const unsigned int word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.d_skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (word == a.skip_value)
+            {
+            if (a.d_published && blockIdx.x == 0 && threadIdx.x == 0)
+                __hip_atomic_store(a.d_published, ((unsigned long long)a.publish_stamp << 32) | (unsigned long long)word, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+            }
+        }
     // Launches over a window of blocks run beside the exchange: one thread reads the predicate word for the whole
     // workgroup (another stream may be raising it at this very moment: the rebuild vote of other ranks arriving; a
     // workgroup must not split over it); the others learn it behind the barrier that follows the set-up below.
