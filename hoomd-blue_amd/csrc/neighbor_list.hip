@@ -1972,8 +1972,35 @@ __global__ void __launch_bounds__(256) update_exclusion_kernel(hmd_update_exclus
 // d_block_group[b]; d_block_group[number of blocks] = all groups.  One workgroup: every thread sums a run of
 // consecutive blocks, the runs are scanned, every thread writes its run.
 constexpr unsigned int BG_THREADS = 1024;
+// Grids with more blocks than the numbering workgroup can keep in its LDS: the group counts of the blocks are worked out
+// by a launch over the whole chip first (one thread per block, its eight cell sizes in flight together) and left in
+// d_block_group, where the numbering kernel turns them into starts (cached == 2).
+__global__ void __launch_bounds__(256) tile_block_counts_kernel(const unsigned int* d_cell_size, hmd_index3d_t ci, unsigned int cell_Nmax, unsigned int* d_block_group)
+    {
+    const unsigned int nbx = (ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (ci.h + hmd::TB_Y - 1) / hmd::TB_Y, nbz = (ci.d + hmd::TB_Z - 1) / hmd::TB_Z;
+    const unsigned int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbx * nby * nbz)
+        return;
+    const unsigned int cx0 = hmd::TB_X * (b % nbx), cy0 = hmd::TB_Y * ((b / nbx) % nby), cz0 = hmd::TB_Z * (b / (nbx * nby));
+    unsigned int v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        {
+        const unsigned int x = cx0 + q % hmd::TB_X, y = cy0 + (q / hmd::TB_X) % hmd::TB_Y, z = cz0 + q / (hmd::TB_X * hmd::TB_Y);
+        v[q] = d_cell_size[(min(z, ci.d - 1u) * ci.h + min(y, ci.h - 1u)) * ci.w + min(x, ci.w - 1u)];
+        }
+    unsigned int members = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        {
+        const unsigned int x = cx0 + q % hmd::TB_X, y = cy0 + (q / hmd::TB_X) % hmd::TB_Y, z = cz0 + q / (hmd::TB_X * hmd::TB_Y);
+        members += (x < ci.w && y < ci.h && z < ci.d) ? min(v[q], cell_Nmax) : 0u;
+        }
+    d_block_group[b] = (members + hmd::TL_GROUP - 1) / hmd::TL_GROUP;
+    }
+
 __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const unsigned int* d_cell_size, hmd_index3d_t ci, unsigned int cell_Nmax,
-                                                                       unsigned int* d_block_group, unsigned int tile_groups, unsigned int* d_tile_overflow, bool cached)
+                                                                       unsigned int* d_block_group, unsigned int tile_groups, unsigned int* d_tile_overflow, unsigned int cached)
     {
     __shared__ unsigned int s_wave[BG_THREADS / 64];
     const unsigned int nbx = (ci.w + hmd::TB_X - 1) / hmd::TB_X, nby = (ci.h + hmd::TB_Y - 1) / hmd::TB_Y, nbz = (ci.d + hmd::TB_Z - 1) / hmd::TB_Z;
@@ -2018,7 +2045,7 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
     // counts first, with neighboring threads on neighboring blocks (when they fit the LDS the launcher provided):
     // every thread then sums and later numbers its run of consecutive blocks from LDS
     extern __shared__ unsigned int s_groups[];
-    if (cached)
+    if (cached == 1u)
         {
         // four blocks per trip: 32 loads in flight per thread
         for (unsigned int b = threadIdx.x; b < nb; b += 4u * BG_THREADS)
@@ -2043,7 +2070,7 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
         }
     unsigned int mine = 0;
     for (unsigned int b = first; b < last; b++)
-        mine += cached ? s_groups[b] : groups_of(b);
+        mine += cached == 1u ? s_groups[b] : (cached == 2u ? d_block_group[b] : groups_of(b));
     // exclusive scan over the threads
     const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int incl = hmd::tile_wave_scan(mine, (int)lane);
@@ -2060,8 +2087,9 @@ __global__ void __launch_bounds__(BG_THREADS) tile_block_groups_kernel(const uns
     unsigned int run = base + incl - mine;
     for (unsigned int b = first; b < last; b++)
         {
+        const unsigned int c = cached == 1u ? s_groups[b] : (cached == 2u ? d_block_group[b] : groups_of(b)); // (read before it is overwritten)
         d_block_group[b] = run;
-        run += cached ? s_groups[b] : groups_of(b);
+        run += c;
         }
     if (threadIdx.x == 0)
         {
@@ -2302,8 +2330,14 @@ extern "C" int hmd_compute_nlist_tiles(const hmd_nlist_tiles_args_t* args, void*
     const unsigned int tile_groups = (unsigned int)(groups_fit - hmd::TL_SLACK_GROUPS);
     // the groups are numbered first (that kernel also clears d_tile_overflow), and the build gives up when they do not fit
     const size_t bg_lds = (size_t)hmd::tile_num_blocks(t.geom.ci) * sizeof(unsigned int);
-    const bool bg_cached = bg_lds <= 60 * 1024;
-    hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), bg_cached ? bg_lds : 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci,
+    // (HOOMD_AMD_BG_LDS_LIMIT: the size in bytes up to which the counts are kept in LDS, for tests of the other path)
+    const char* bg_env = std::getenv("HOOMD_AMD_BG_LDS_LIMIT");
+    const size_t bg_limit = bg_env ? (size_t)std::atol(bg_env) : (size_t)60 * 1024;
+    const unsigned int bg_cached = bg_lds <= std::min<size_t>(bg_limit, 60 * 1024) ? 1u : 2u;
+    if (bg_cached == 2u)
+        hipLaunchKernelGGL(tile_block_counts_kernel, dim3(hmd_div_up(hmd::tile_num_blocks(t.geom.ci), 256)), dim3(256), 0, (hipStream_t)stream, t.geom.d_cell_size,
+                           t.geom.ci, t.geom.cli.w, const_cast<unsigned int*>(t.geom.d_block_group));
+    hipLaunchKernelGGL(tile_block_groups_kernel, dim3(1), dim3(BG_THREADS), bg_cached == 1u ? bg_lds : 0, (hipStream_t)stream, t.geom.d_cell_size, t.geom.ci,
                        t.geom.cli.w, const_cast<unsigned int*>(t.geom.d_block_group), tile_groups, t.d_tile_overflow, bg_cached);
     HMD_REQUIRE(!t.d_n_ex_idx || (t.d_ex_list_idx && t.exli.w >= t.N), HMD_ERR_INVALID_ARGUMENT,
                 "hmd_compute_nlist_tiles: exclusions need d_ex_list_idx and an indexer at least N wide");

@@ -179,6 +179,26 @@ def test_tile_lj_forces_match_oracle(K, A, shift_mode, ntypes):
     assert _rel_err(F2.cpu().numpy(), F_ref) < F_RTOL * 1e-4
 
 
+def test_group_numbering_of_grids_too_large_for_the_lds(K, A, monkeypatch):
+    """Grids with more blocks than the numbering workgroup keeps in LDS get their group counts from a launch of their
+    own (tile_block_counts_kernel); forced here on a small grid: same numbering, same rows."""
+    xyz, typ, L = liquid(14, seed=9)
+    N = len(xyz)
+    gbox, obox = boxes(A, L)
+    pos_t = torch.from_numpy(orc.pack_pos(xyz, typ)).cuda()
+    dim = orc.cell_dimensions(obox, 2.9, 1, (0, 0, 0), 3)
+    adj = torch.as_tensor(orc.cell_adj(dim, 1, 3).view(np.int32), device="cuda")
+    out = []
+    for limit in (None, "0"):
+        if limit is not None:
+            monkeypatch.setenv("HOOMD_AMD_BG_LDS_LIMIT", limit)
+        cl = K.cell_list_auto(pos_t, N, 0, gbox, dim, want_idx=True)
+        tl = K.nlist_tiles(pos_t, N, gbox, [[2.5]], 0.4, cl, adj)
+        out.append((tl["block_group"].cpu().numpy().copy(), tl["n_neigh"].cpu().numpy().copy(), expanded_sets(K, tl, N, gbox)))
+    assert out[0][0][-1] > 0 and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert all(np.array_equal(x, y) for x, y in zip(out[0][2], out[1][2])) and len(out[0][2]) == N
+
+
 @pytest.mark.parametrize("ntypes", [1, 2, 3])
 def test_tile_forces_with_densely_filled_cells(K, A, ntypes):
     """More than 32 members in most cells (density 1.3: the staging takes the members past the 32nd of a cell in extra
