@@ -26,9 +26,17 @@ __global__ void __launch_bounds__(256) cell_list_kernel(hmd_cell_list_args_t a)
     unsigned int bin = 0xffffffffu;
     double4 p = make_double4(0, 0, 0, 0);
 
+    // (what goes into the cell besides the position is asked for here, with the position: behind the atomic below it
+    // would be a second round trip to memory for every wave)
+    unsigned int body = HMD_NO_BODY;
+    double charge = 0.0;
     if (active)
         {
         p = hmd_ld4(a.d_pos + idx);
+        if (a.d_type_body && a.d_body)
+            body = a.d_body[idx];
+        if (a.flag_charge)
+            charge = a.d_charge[idx];
         if (isnan(p.x) || isnan(p.y) || isnan(p.z))
             {
             a.d_conditions->y = idx + 1;
@@ -99,7 +107,7 @@ __global__ void __launch_bounds__(256) cell_list_kernel(hmd_cell_list_args_t a)
         const unsigned int w = hmd_idx2(a.cli, slot, bin);
         double flag;
         if (a.flag_charge)
-            flag = a.d_charge[idx];
+            flag = charge;
         else if (a.flag_type)
             flag = p.w;
         else
@@ -108,7 +116,6 @@ __global__ void __launch_bounds__(256) cell_list_kernel(hmd_cell_list_args_t a)
             hmd_st4(a.d_xyzf + w, p.x, p.y, p.z, flag);
         if (a.d_type_body)
             {
-            const unsigned int body = a.d_body ? a.d_body[idx] : HMD_NO_BODY;
             *reinterpret_cast<uint2*>(a.d_type_body + w) = make_uint2(hmd_double_as_uint(p.w), body);
             }
         if (a.d_cell_orientation)
